@@ -1,0 +1,136 @@
+"""ctypes binding of oracle/libtrueknn_oracle.so (built by ``make -C oracle``)."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libtrueknn_oracle.so")
+
+ORDER_ASCENDING, ORDER_DESCENDING, ORDER_SHUFFLED = 0, 1, 2
+
+# samples/s01-trueknn/GeomTypes.h:22-28 -- 24-byte record, 4 bytes of padding before the int64
+NEIGH_DTYPE = np.dtype(
+    {
+        "names": ["ind", "dist", "numNeighbors", "intersections"],
+        "formats": [np.int32, np.float32, np.int32, np.int64],
+        "offsets": [0, 4, 8, 16],
+        "itemsize": 24,
+    }
+)
+
+
+class OracleError(RuntimeError):
+    pass
+
+
+def build(force=False):
+    """Compile the C restatement (gcc); building the checker is not using it."""
+    src = os.path.join(_HERE, "trueknn_oracle.c")
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-s", "clean", "all"])
+    return _SO
+
+
+_lib = None
+
+
+def _load():
+    global _lib
+    if _lib is None:
+        build()
+        lib = ctypes.CDLL(_SO)
+        lib.tkref_sizeof_neigh.restype = ctypes.c_int
+        lib.tkref_num_threads.restype = ctypes.c_int
+        lib.tkref_distance.restype = ctypes.c_float
+        lib.tkref_distance.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+        lib.tkref_init_rows.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int]
+        lib.tkref_trueknn.restype = ctypes.c_int
+        lib.tkref_trueknn.argtypes = [
+            ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_float, ctypes.c_int,
+            ctypes.c_uint64, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_void_p,
+            ctypes.c_void_p,
+        ]
+        lib.tkref_bruteforce.restype = ctypes.c_int
+        lib.tkref_bruteforce.argtypes = [
+            ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_void_p, ctypes.c_int64,
+            ctypes.c_void_p, ctypes.c_void_p,
+        ]
+        assert lib.tkref_sizeof_neigh() == NEIGH_DTYPE.itemsize
+        _lib = lib
+    return _lib
+
+
+def num_threads():
+    return int(_load().tkref_num_threads())
+
+
+def _points(xyz):
+    xyz = np.ascontiguousarray(xyz, dtype=np.float32)
+    if xyz.ndim != 2 or xyz.shape[1] not in (2, 3):
+        raise ValueError("points must be (n,2) or (n,3)")
+    if xyz.shape[1] == 2:  # hostCode.cpp:115-118
+        xyz = np.ascontiguousarray(np.concatenate([xyz, np.zeros((len(xyz), 1), np.float32)], 1))
+    return xyz
+
+
+def distance(c_prim, org):
+    a = np.ascontiguousarray(c_prim, dtype=np.float32)
+    b = np.ascontiguousarray(org, dtype=np.float32)
+    return float(_load().tkref_distance(a.ctypes.data, b.ctypes.data))
+
+
+def trueknn(xyz, k, start_radius, order=ORDER_ASCENDING, seed=0, query_ids=None, max_rounds=64):
+    """Run the restated solve.  Returns dict(fb, idx, dist, intersections, rounds, final_radius).
+
+    ``fb`` is the reference's frameBuffer (n*k Neigh records) after the last round; ``idx`` /
+    ``dist`` / ``intersections`` are views of it reshaped (n,k) / (n,k) / (n,).  With
+    ``query_ids`` only those rows are solved (others keep their initial state).
+    """
+    lib = _load()
+    xyz = _points(xyz)
+    n = len(xyz)
+    fb = np.zeros(n * k, dtype=NEIGH_DTYPE)
+    lib.tkref_init_rows(fb.ctypes.data, n, k)
+    q = None
+    nq = n
+    if query_ids is not None:
+        q = np.ascontiguousarray(query_ids, dtype=np.int32)
+        nq = len(q)
+    fr = ctypes.c_float(0)
+    rc = lib.tkref_trueknn(
+        xyz.ctypes.data, n, k, ctypes.c_float(start_radius), order, seed,
+        None if q is None else q.ctypes.data, nq, max_rounds, fb.ctypes.data, ctypes.byref(fr),
+    )
+    if rc < 0:
+        raise OracleError({-1: "bad arguments", -2: "out of memory",
+                           -3: "max_rounds reached with unfinished queries"}.get(rc, str(rc)))
+    rows = fb.reshape(n, k)
+    return {
+        "fb": fb,
+        "idx": rows["ind"],
+        "dist": rows["dist"],
+        "intersections": rows["intersections"][:, 0],
+        "num_neighbors": rows["numNeighbors"][:, 0],
+        "rounds": rc,
+        "final_radius": float(fr.value),
+    }
+
+
+def bruteforce_knn(xyz, k, query_ids=None):
+    lib = _load()
+    xyz = _points(xyz)
+    n = len(xyz)
+    q = None
+    nq = n
+    if query_ids is not None:
+        q = np.ascontiguousarray(query_ids, dtype=np.int32)
+        nq = len(q)
+    idx = np.empty((nq, k), np.int32)
+    dist = np.empty((nq, k), np.float32)
+    rc = lib.tkref_bruteforce(xyz.ctypes.data, n, k, None if q is None else q.ctypes.data, nq,
+                              idx.ctypes.data, dist.ctypes.data)
+    if rc:
+        raise OracleError("bruteforce failed: %d" % rc)
+    return idx, dist
