@@ -1,0 +1,123 @@
+/*
+ * owlknn.h -- C-ABI of the MI355X-native TrueKNN engine (libowl_mi355x.so).
+ *
+ * This is the hot path of vani-nag/OWLRayTracing's samples/s01-trueknn, taken as ONE unit:
+ *
+ *   reference                                               here
+ *   ------------------------------------------------------  --------------------------------
+ *   owlDeviceBufferCreate(Sphere[n])  hostCode.cpp:165-166   tknnBuild: points already in HBM
+ *   owlUserGeomGroupCreate + owlGroupBuildAccel (+ instance  tknnBuild: HIP LBVH (Morton sort +
+ *     group)  hostCode.cpp:201-206 -> bounds program           radix tree) over the centres; the
+ *     deviceCode.cu:38-56 + optixAccelBuild                    radius is applied at test time
+ *     (owl/UserGeomGroup.cpp:161-217)
+ *   while(!foundKNN){ owlLaunch2D; scan fb; radius*=2;       tknnSolve: the whole radius-doubling
+ *     owlGeomSet1f; owlGroupRefitAccel x2 }                    solve, rounds resolved on the device
+ *     hostCode.cpp:285-340 around __raygen__rayGen /
+ *     __intersection__Spheres  deviceCode.cu:62-153
+ *   frameBuffer of Neigh[n*k]  GeomTypes.h:22-28             d_fb (same 24-byte records) and/or
+ *                                                            compact idx/dist/intersections
+ *
+ * The same library also exports the reference's own owl* entry points (include/owl/owl_host.h),
+ * which run user raygen / intersect / bounds programs over the same LBVH; the tknn* calls are the
+ * fused form of the loop above and give bit-identical rows (modulo the order of exact ties, which
+ * the reference leaves to traversal order; tknn* always orders ties by index).
+ *
+ * Conventions: plain C, pointers and sizes only.  `d_` pointers are device (HBM) addresses valid
+ * on the engine's device.  `stream` is a hipStream_t passed as void* (NULL = default stream).
+ * Every call returns 0 on success or a negative TKNN_E_* code; tknnLastError() gives the text.
+ * Nothing here falls back to the CPU.
+ */
+#ifndef OWLKNN_H
+#define OWLKNN_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TKNN_API __attribute__((visibility("default")))
+
+typedef struct tknnEngine_t *tknnEngine;
+
+/* GeomTypes.h:22-28: 24-byte result record; only slot [q*k+0] carries numNeighbors/intersections */
+typedef struct {
+  int32_t ind;
+  float dist;
+  int32_t numNeighbors;
+  int32_t pad_;
+  int64_t intersections;
+} tknnNeigh;
+
+enum {
+  TKNN_OK = 0,
+  TKNN_E_ARG = -1,      /* bad argument (null pointer, n <= k, radius not finite-positive, ...)  */
+  TKNN_E_HIP = -2,      /* a HIP call failed; no device, out of memory, launch failure           */
+  TKNN_E_STATE = -3,    /* call order: solve before build, ...                                   */
+  TKNN_E_ROUNDS = -4,   /* max_rounds reached with unfinished queries (reference: endless loop)  */
+  TKNN_E_UNSUPPORTED = -5 /* k larger than the register-resident list of this build (TKNN_MAX_K) */
+};
+
+#define TKNN_MAX_K 64
+
+/* which traversal kernel tknnSolve uses */
+enum {
+  TKNN_KERNEL_AUTO = 0,
+  TKNN_KERNEL_LANE = 1,  /* one query per lane, stackless rope traversal, one launch per round    */
+  TKNN_KERNEL_WAVE = 2   /* one 64-query packet per wave, persistent, all rounds in one launch    */
+};
+
+typedef struct {
+  int32_t rounds;              /* radius levels needed = rounds of the reference loop             */
+  float final_radius;          /* radius of the last round                                        */
+  int64_t total_intersections; /* sum of Neigh.intersections = intersection-program calls         */
+  int64_t node_tests;          /* box tests against BVH nodes (wave kernel: per packet)           */
+  int64_t point_tests;         /* exact point-in-box tests executed (>= total_intersections)      */
+  float solve_ms;              /* device time of the traversal launches, HIP events on `stream`   */
+  float dominant_kernel_ms;    /* average duration of one launch of the dominant kernel           */
+  int32_t dominant_kernel_launches;
+  int32_t kernel_used;         /* TKNN_KERNEL_*                                                   */
+  int32_t list_capacity;       /* register k-list size the kernel was instantiated with           */
+} tknnSolveInfo;
+
+typedef struct {
+  float build_ms;        /* device time of the LBVH build                                         */
+  int64_t device_bytes;  /* HBM held by the tree                                                  */
+  int32_t n;
+} tknnBuildInfo;
+
+TKNN_API const char *tknnLastError(void);
+TKNN_API int tknnDeviceCount(void);
+
+/* engine on the current HIP device (hipSetDevice before the call picks it) */
+TKNN_API int tknnCreate(tknnEngine *out);
+TKNN_API void tknnDestroy(tknnEngine e);
+
+/* Build the LBVH over n points.  d_xyz: n packed fp32 triples (the Sphere buffer, 12 B each; 2-D
+ * data carries z = 0 as in hostCode.cpp:115-118).  The engine keeps its own Morton-ordered copy;
+ * d_xyz may be freed afterwards. */
+TKNN_API int tknnBuild(tknnEngine e, const float *d_xyz, int64_t n, tknnBuildInfo *info, void *stream);
+
+/* Solve TrueKNN for every point (queries = points, deviceCode.cu:140-153).
+ *   k, start_radius   as argv[5], argv[4] of the sample; n > k and 0 < start_radius < inf required
+ *   max_rounds        give up (TKNN_E_ROUNDS) after this many radius levels; <= 0 means 64
+ *   d_idx, d_dist     n*k each, row q = neighbours of point q (caller's index), ascending
+ *                     (dist, index); either may be NULL
+ *   d_intersections   n, Neigh.intersections of slot 0 of each row; may be NULL
+ *   d_fb              n*k tknnNeigh records in the state the reference's frameBuffer has after its
+ *                     last round; may be NULL
+ */
+TKNN_API int tknnSolve(tknnEngine e, int k, float start_radius, int kernel, int max_rounds,
+                       int32_t *d_idx, float *d_dist, int64_t *d_intersections, tknnNeigh *d_fb,
+                       tknnSolveInfo *info, void *stream);
+
+/* Test / debug export of the tree to host memory (any pointer may be NULL):
+ *   nodes      (n-1) x 8 dwords {lo[3], split, hi[3], other}   (include/owl/lbvh_device.h)
+ *   rope_node  n-1, rope_leaf n, prim_id n (caller index of sorted slot)            */
+TKNN_API int tknnExportTree(tknnEngine e, void *nodes, int32_t *rope_node, int32_t *rope_leaf,
+                            int32_t *prim_id, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OWLKNN_H */

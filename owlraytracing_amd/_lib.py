@@ -1,0 +1,85 @@
+"""ctypes binding of libowl_mi355x.so (the C-ABI declared in include/owlknn.h).
+
+There is no fallback: if the library has not been built, or no MI355X is visible when an engine is
+created, the call raises.  Build with ``python -c "import __graft_entry__ as g; g.build()"`` or
+``make -C owlraytracing_amd/csrc``.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libowl_mi355x.so")
+
+KERNEL_AUTO, KERNEL_LANE, KERNEL_WAVE = 0, 1, 2
+MAX_K = 64
+
+
+class TknnError(RuntimeError):
+    def __init__(self, code, message):
+        super().__init__("tknn error %d: %s" % (code, message))
+        self.code = code
+
+
+class SolveInfo(ctypes.Structure):
+    _fields_ = [
+        ("rounds", ctypes.c_int32),
+        ("final_radius", ctypes.c_float),
+        ("total_intersections", ctypes.c_int64),
+        ("node_tests", ctypes.c_int64),
+        ("point_tests", ctypes.c_int64),
+        ("solve_ms", ctypes.c_float),
+        ("dominant_kernel_ms", ctypes.c_float),
+        ("dominant_kernel_launches", ctypes.c_int32),
+        ("kernel_used", ctypes.c_int32),
+        ("list_capacity", ctypes.c_int32),
+    ]
+
+    def as_dict(self):
+        return {name: getattr(self, name) for name, _ in self._fields_}
+
+
+class BuildInfo(ctypes.Structure):
+    _fields_ = [("build_ms", ctypes.c_float), ("device_bytes", ctypes.c_int64), ("n", ctypes.c_int32)]
+
+    def as_dict(self):
+        return {name: getattr(self, name) for name, _ in self._fields_}
+
+
+# every symbol include/owlknn.h declares, with its signature
+SIGNATURES = {
+    "tknnLastError": (ctypes.c_char_p, []),
+    "tknnDeviceCount": (ctypes.c_int, []),
+    "tknnCreate": (ctypes.c_int, [ctypes.POINTER(ctypes.c_void_p)]),
+    "tknnDestroy": (None, [ctypes.c_void_p]),
+    "tknnBuild": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64,
+                                 ctypes.POINTER(BuildInfo), ctypes.c_void_p]),
+    "tknnSolve": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_int,
+                                 ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                 ctypes.c_void_p, ctypes.POINTER(SolveInfo), ctypes.c_void_p]),
+    "tknnExportTree": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                      ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
+}
+
+_lib = None
+
+
+def load():
+    """Load the shared library (no GPU needed for loading itself)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                "%s not found: build the HIP extension first (make -C owlraytracing_amd/csrc); "
+                "there is no CPU fallback" % LIB_PATH)
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)  # AttributeError if the .so lacks a declared symbol
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        raise TknnError(rc, (load().tknnLastError() or b"").decode())

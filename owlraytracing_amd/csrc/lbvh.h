@@ -1,0 +1,80 @@
+// lbvh.h -- host API of the HIP LBVH builder (Morton sort + Karras radix tree + fence-free fit).
+// Replaces what the reference delegates to optixAccelBuild (owl/UserGeomGroup.cpp:161-217 BUILD,
+// :75-76/:199 UPDATE on refit).  Device layout: include/owl/lbvh_device.h.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+
+#include "owl/lbvh_device.h"
+
+namespace owlmi {
+
+struct HipError {
+  std::string what;
+};
+
+#define OWLMI_HIP(call)                                                                        \
+  do {                                                                                         \
+    hipError_t e_ = (call);                                                                    \
+    if (e_ != hipSuccess)                                                                      \
+      throw ::owlmi::HipError{std::string(#call) + " failed: " + hipGetErrorString(e_) + " (" + \
+                              __FILE__ + ":" + std::to_string(__LINE__) + ")"};                \
+  } while (0)
+
+// One LBVH over n primitives.  Two flavours of leaf payload:
+//   points: primitives are points (the TrueKNN / DBSCAN pattern: every box is centre +- rad with
+//           one shared rad).  Node boxes bound the *centres*; the radius is added at test time,
+//           so changing it needs no refit at all.
+//   boxes : arbitrary per-primitive AABBs as written by a user bounds program; node boxes bound
+//           the boxes; refit() recomputes them on the same topology (OptiX UPDATE semantics).
+class Lbvh {
+ public:
+  Lbvh() = default;
+  ~Lbvh();
+  Lbvh(const Lbvh &) = delete;
+  Lbvh &operator=(const Lbvh &) = delete;
+
+  // xyz: device pointer to n packed fp32 triples (the reference's Sphere buffer, 12 B/point).
+  void build_from_points(const float *d_xyz, int64_t n, hipStream_t stream);
+  // boxes: device pointer to n {lo[3],hi[3]} (24 B, owl::box3f) in caller primitive order.
+  void build_from_boxes(const LbvhBox *d_boxes, int64_t n, hipStream_t stream);
+  // same topology, new boxes (only for build_from_boxes trees)
+  void refit_boxes(const LbvhBox *d_boxes, hipStream_t stream);
+
+  LbvhView view() const;
+  int64_t size() const { return n_; }
+  bool built() const { return built_; }
+  bool has_points() const { return points_ != nullptr && point_mode_; }
+  size_t device_bytes() const { return bytes_; }
+
+  // debug / test export (host copies)
+  void download(LbvhNode *nodes, int32_t *rope_node, int32_t *rope_leaf, int32_t *prim_id,
+                hipStream_t stream) const;
+
+ private:
+  void reserve(int64_t n);
+  void release();
+  void sort_and_tree(hipStream_t stream);
+  void fit(hipStream_t stream);
+
+  int64_t n_ = 0, cap_ = 0;
+  bool built_ = false, point_mode_ = false;
+  size_t bytes_ = 0;
+  float *scene_ = nullptr;     // 6 floats + partials
+  float *partials_ = nullptr;  // kPartialBlocks*6
+  uint64_t *codes_ = nullptr, *codes_alt_ = nullptr;
+  uint32_t *order_ = nullptr, *order_alt_ = nullptr;
+  void *sort_tmp_ = nullptr;
+  size_t sort_tmp_bytes_ = 0;
+  LbvhNode *nodes_ = nullptr;
+  int32_t *split_owner_ = nullptr, *rope_node_ = nullptr, *rope_leaf_ = nullptr;
+  LbvhPoint *points_ = nullptr;
+  LbvhBox *boxes_ = nullptr;  // sorted boxes (box mode)
+  int32_t *prim_id_ = nullptr;
+  LbvhBox *table_[4] = {nullptr, nullptr, nullptr, nullptr};
+  int64_t table_n_[4] = {0, 0, 0, 0};
+};
+
+}  // namespace owlmi

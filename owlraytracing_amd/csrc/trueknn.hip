@@ -1,0 +1,368 @@
+// trueknn.hip -- the TrueKNN engine behind include/owlknn.h: LBVH build, the per-round "lane"
+// kernel (one query per lane, stackless rope traversal) and the result writers.  The persistent
+// wave-packet kernel lives in trueknn_wave.hip.
+//
+// Reference functions this file replaces (samples/s01-trueknn):
+//   deviceCode.cu:140-153  __raygen__rayGen            -> active test + point query per lane
+//   owl_device.h:150-174   optixTrace (RT cores)       -> rope traversal of the LBVH
+//   deviceCode.cu:62-138   __intersection__Spheres     -> box test + register k-list insert
+//   hostCode.cpp:285-340   round loop                  -> Engine::solve_lane
+#include "trueknn_engine.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+
+namespace owlmi {
+
+namespace {
+
+constexpr int kLaneBlock = 256;
+
+struct LaneRoundArgs {
+  LbvhView bvh;
+  float radius;
+  int k;
+  uint8_t *done;           // per sorted slot
+  int64_t *isect_sorted;   // per sorted slot, accumulated over rounds
+  int32_t *out_idx;        // n*k, caller order (may be null)
+  float *out_dist;         // n*k (may be null)
+  int64_t *out_isect;      // n (may be null)
+  tknnNeigh *out_fb;       // n*k (may be null)
+  unsigned long long *counters;  // [0] unfinished, [1] node tests, [2] point tests, [3] sum isect
+};
+
+template <int K>
+__device__ __forceinline__ void write_row(const LaneRoundArgs &a, int32_t qid, const KList<K> &list,
+                                          int64_t isect) {
+  const int k = a.k;
+  const int64_t base = (int64_t)qid * k;
+#pragma unroll
+  for (int j = 0; j < K; j++) {
+    if (j < k) {
+      int32_t prim = knn_key_prim(list.key[j]);
+      float d = knn_key_dist(list.key[j]);
+      if (a.out_idx) a.out_idx[base + j] = prim;
+      if (a.out_dist) a.out_dist[base + j] = d;
+      if (a.out_fb) {
+        // final state of the reference's frameBuffer: slot 0 carries numNeighbors (0 = done) and
+        // the intersection counter, other slots keep their initial {k, 0}  (deviceCode.cu:74,118)
+        tknnNeigh e;
+        e.ind = prim;
+        e.dist = d;
+        e.numNeighbors = j == 0 ? 0 : k;
+        e.pad_ = 0;
+        e.intersections = j == 0 ? isect : 0;
+        a.out_fb[base + j] = e;
+      }
+    }
+  }
+  if (a.out_isect) a.out_isect[qid] = isect;
+}
+
+template <int K>
+__global__ void __launch_bounds__(kLaneBlock) lane_round_kernel(LaneRoundArgs a) {
+  const int32_t t = blockIdx.x * kLaneBlock + threadIdx.x;
+  const LbvhView &bvh = a.bvh;
+  // deviceCode.cu:148: finished queries launch no ray.  Inactive lanes fall through to the
+  // wave-wide counter reduction at the end instead of returning.
+  const bool active = t < bvh.n && !a.done[t];
+  LbvhPoint q = {0.f, 0.f, 0.f, -1};
+  if (active) q = bvh.points[t];
+  const float r = a.radius;
+  KList<K> list;
+  list.clear();
+  int32_t cnt = 0, others = 0;
+  uint32_t node_tests = 0, point_tests = 0;
+  int32_t ref = active ? bvh.root : LBVH_END;
+  while (ref != LBVH_END) {
+    if (ref >= 0) {
+      const LbvhNode nd = bvh.nodes[ref];
+      node_tests++;
+      // conservative: any point p in the node has lo <= c_p <= hi, and fp32 rounding is monotone,
+      // so fl(c_p - r) >= fl(lo - r) and fl(c_p + r) <= fl(hi + r)
+      bool hit = (nd.lo[0] - r <= q.x) & (q.x <= nd.hi[0] + r) & (nd.lo[1] - r <= q.y) &
+                 (q.y <= nd.hi[1] + r) & (nd.lo[2] - r <= q.z) & (q.z <= nd.hi[2] + r);
+      ref = hit ? lbvh_left_ref(ref, nd) : bvh.rope_node[ref];
+    } else {
+      const int32_t slot = ~ref;
+      const LbvhPoint p = bvh.points[slot];
+      point_tests++;
+      if (knn_in_box(p.x, p.y, p.z, r, q.x, q.y, q.z)) {
+        cnt++;                 // deviceCode.cu:74
+        if (p.id != q.id) {    // deviceCode.cu:103
+          others++;
+          float d = knn_sqrt(knn_dist2(p.x, p.y, p.z, q.x, q.y, q.z));
+          list.insert(knn_key(d, p.id));
+        }
+      }
+      ref = bvh.rope_leaf[slot];
+    }
+  }
+  int64_t isect = 0;
+  bool finished = false;
+  if (active) {
+    isect = a.isect_sorted[t] + cnt;
+    a.isect_sorted[t] = isect;
+    finished = others >= a.k;  // k insertions happened <=> numNeighbors reached 0
+    if (finished) {
+      a.done[t] = 1;
+      write_row<K>(a, q.id, list, isect);
+    }
+  }
+  // wave-aggregated counters (all 64 lanes are here)
+  unsigned long long unfinished = __popcll(__ballot(active && !finished));
+  unsigned long long nt = node_tests, pt = point_tests, si = finished ? (unsigned long long)isect : 0ull;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    nt += __shfl_xor(nt, off);
+    pt += __shfl_xor(pt, off);
+    si += __shfl_xor(si, off);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    if (unfinished) atomicAdd(&a.counters[0], unfinished);
+    atomicAdd(&a.counters[1], nt);
+    atomicAdd(&a.counters[2], pt);
+    if (si) atomicAdd(&a.counters[3], si);
+  }
+}
+
+template <int K>
+void launch_lane(const LaneRoundArgs &a, hipStream_t s) {
+  unsigned blocks = (unsigned)((a.bvh.n + kLaneBlock - 1) / kLaneBlock);
+  hipLaunchKernelGGL(lane_round_kernel<K>, dim3(blocks), dim3(kLaneBlock), 0, s, a);
+}
+
+}  // namespace
+
+int list_capacity_for(int k) {
+  static const int caps[] = {1, 2, 4, 5, 8, 10, 16, 24, 32, 64};
+  for (int c : caps)
+    if (k <= c) return c;
+  return -1;
+}
+
+Engine::Engine() {
+  OWLMI_HIP(hipGetDevice(&device_));
+  OWLMI_HIP(hipEventCreate(&ev_a_));
+  OWLMI_HIP(hipEventCreate(&ev_b_));
+  OWLMI_HIP(hipMalloc((void **)&counters_, 16 * sizeof(unsigned long long)));
+  OWLMI_HIP(hipHostMalloc((void **)&h_counters_, 16 * sizeof(unsigned long long)));
+  if (const char *e = getenv("TKNN_LEAF_MAX")) {
+    int v = atoi(e);
+    if (v >= 1 && v <= 64) wave_leaf_max_ = v;
+  }
+}
+
+Engine::~Engine() {
+  if (done_) (void)hipFree(done_);
+  if (isect_sorted_) (void)hipFree(isect_sorted_);
+  if (counters_) (void)hipFree(counters_);
+  if (h_counters_) (void)hipHostFree(h_counters_);
+  if (wave_ws_) (void)hipFree(wave_ws_);
+  if (ev_a_) (void)hipEventDestroy(ev_a_);
+  if (ev_b_) (void)hipEventDestroy(ev_b_);
+}
+
+void Engine::build(const float *d_xyz, int64_t n, tknnBuildInfo *info, hipStream_t s) {
+  OWLMI_HIP(hipEventRecord(ev_a_, s));
+  bvh_.build_from_points(d_xyz, n, s);
+  OWLMI_HIP(hipEventRecord(ev_b_, s));
+  if (n > state_cap_) {
+    if (done_) (void)hipFree(done_);
+    if (isect_sorted_) (void)hipFree(isect_sorted_);
+    done_ = nullptr;
+    isect_sorted_ = nullptr;
+    OWLMI_HIP(hipMalloc((void **)&done_, (size_t)n));
+    OWLMI_HIP(hipMalloc((void **)&isect_sorted_, (size_t)n * sizeof(int64_t)));
+    state_cap_ = n;
+  }
+  OWLMI_HIP(hipEventSynchronize(ev_b_));
+  if (info) {
+    float ms = 0;
+    OWLMI_HIP(hipEventElapsedTime(&ms, ev_a_, ev_b_));
+    info->build_ms = ms;
+    info->device_bytes = (int64_t)bvh_.device_bytes();
+    info->n = (int32_t)n;
+  }
+}
+
+void Engine::solve_lane(const SolveArgs &sa, tknnSolveInfo *info, hipStream_t s) {
+  const int64_t n = bvh_.size();
+  const int cap = list_capacity_for(sa.k);
+  OWLMI_HIP(hipMemsetAsync(done_, 0, (size_t)n, s));
+  OWLMI_HIP(hipMemsetAsync(isect_sorted_, 0, (size_t)n * sizeof(int64_t), s));
+  OWLMI_HIP(hipMemsetAsync(counters_, 0, 16 * sizeof(unsigned long long), s));
+  LaneRoundArgs a;
+  a.bvh = bvh_.view();
+  a.k = sa.k;
+  a.done = done_;
+  a.isect_sorted = isect_sorted_;
+  a.out_idx = sa.d_idx;
+  a.out_dist = sa.d_dist;
+  a.out_isect = sa.d_isect;
+  a.out_fb = sa.d_fb;
+  a.counters = counters_;
+  float radius = sa.start_radius, total_ms = 0;
+  int rounds = 0;
+  for (;;) {
+    if (rounds >= sa.max_rounds) throw RoundsExceeded{};
+    rounds++;
+    a.radius = radius;
+    OWLMI_HIP(hipMemsetAsync(counters_, 0, sizeof(unsigned long long), s));  // [0] only
+    OWLMI_HIP(hipEventRecord(ev_a_, s));
+    switch (cap) {
+      case 1: launch_lane<1>(a, s); break;
+      case 2: launch_lane<2>(a, s); break;
+      case 4: launch_lane<4>(a, s); break;
+      case 5: launch_lane<5>(a, s); break;
+      case 8: launch_lane<8>(a, s); break;
+      case 10: launch_lane<10>(a, s); break;
+      case 16: launch_lane<16>(a, s); break;
+      case 24: launch_lane<24>(a, s); break;
+      case 32: launch_lane<32>(a, s); break;
+      default: launch_lane<64>(a, s); break;
+    }
+    OWLMI_HIP(hipGetLastError());
+    OWLMI_HIP(hipEventRecord(ev_b_, s));
+    // hostCode.cpp:310-330: the host decides about another round from the result state
+    OWLMI_HIP(hipMemcpyAsync(h_counters_, counters_, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+    OWLMI_HIP(hipStreamSynchronize(s));
+    float ms = 0;
+    OWLMI_HIP(hipEventElapsedTime(&ms, ev_a_, ev_b_));
+    total_ms += ms;
+    if (h_counters_[0] == 0) break;
+    radius *= 2;  // hostCode.cpp:321 (fp32)
+  }
+  if (info) {
+    info->rounds = rounds;
+    info->final_radius = radius;
+    info->node_tests = (int64_t)h_counters_[1];
+    info->point_tests = (int64_t)h_counters_[2];
+    info->total_intersections = (int64_t)h_counters_[3];
+    info->solve_ms = total_ms;
+    info->dominant_kernel_ms = total_ms / rounds;
+    info->dominant_kernel_launches = rounds;
+    info->kernel_used = TKNN_KERNEL_LANE;
+    info->list_capacity = cap;
+  }
+}
+
+void Engine::solve(const SolveArgs &sa, int kernel, tknnSolveInfo *info, hipStream_t s) {
+  if (kernel == TKNN_KERNEL_AUTO) kernel = wave_kernel_available() ? TKNN_KERNEL_WAVE : TKNN_KERNEL_LANE;
+  if (kernel == TKNN_KERNEL_WAVE)
+    solve_wave(sa, info, s);
+  else
+    solve_lane(sa, info, s);
+}
+
+}  // namespace owlmi
+
+// ------------------------------------------------------------------------------------------
+// C-ABI
+// ------------------------------------------------------------------------------------------
+using owlmi::Engine;
+
+static thread_local std::string g_last_error;
+
+struct tknnEngine_t {
+  Engine impl;
+};
+
+template <typename F>
+static int guarded(F &&f) {
+  try {
+    f();
+    return TKNN_OK;
+  } catch (const owlmi::HipError &e) {
+    g_last_error = e.what;
+    return TKNN_E_HIP;
+  } catch (const owlmi::RoundsExceeded &) {
+    g_last_error = "max_rounds reached with unfinished queries (the reference loops forever here, e.g. n <= k)";
+    return TKNN_E_ROUNDS;
+  } catch (const owlmi::ArgError &e) {
+    g_last_error = e.what;
+    return e.code;
+  } catch (const std::exception &e) {
+    g_last_error = e.what();
+    return TKNN_E_HIP;
+  }
+}
+
+extern "C" {
+
+const char *tknnLastError(void) { return g_last_error.c_str(); }
+
+int tknnDeviceCount(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+int tknnCreate(tknnEngine *out) {
+  if (!out) {
+    g_last_error = "tknnCreate: out is NULL";
+    return TKNN_E_ARG;
+  }
+  *out = nullptr;
+  return guarded([&] {
+    int n = 0;
+    OWLMI_HIP(hipGetDeviceCount(&n));
+    if (n <= 0) throw owlmi::HipError{"no HIP device visible: the TrueKNN engine has no CPU fallback"};
+    *out = new tknnEngine_t();
+  });
+}
+
+void tknnDestroy(tknnEngine e) { delete e; }
+
+int tknnBuild(tknnEngine e, const float *d_xyz, int64_t n, tknnBuildInfo *info, void *stream) {
+  if (!e || !d_xyz || n <= 0 || n >= 0x7fffffffLL) {
+    g_last_error = "tknnBuild: need an engine, a device pointer and 0 < n < 2^31-1";
+    return TKNN_E_ARG;
+  }
+  return guarded([&] { e->impl.build(d_xyz, n, info, (hipStream_t)stream); });
+}
+
+int tknnSolve(tknnEngine e, int k, float start_radius, int kernel, int max_rounds, int32_t *d_idx,
+              float *d_dist, int64_t *d_intersections, tknnNeigh *d_fb, tknnSolveInfo *info, void *stream) {
+  if (!e) {
+    g_last_error = "tknnSolve: engine is NULL";
+    return TKNN_E_ARG;
+  }
+  return guarded([&] {
+    if (!e->impl.built()) throw owlmi::ArgError{TKNN_E_STATE, "tknnSolve: call tknnBuild first"};
+    if (k <= 0) throw owlmi::ArgError{TKNN_E_ARG, "tknnSolve: k must be positive"};
+    if (k > TKNN_MAX_K) throw owlmi::ArgError{TKNN_E_UNSUPPORTED, "tknnSolve: k exceeds TKNN_MAX_K"};
+    if ((int64_t)k >= e->impl.size())
+      throw owlmi::ArgError{TKNN_E_ARG, "tknnSolve: need n > k (the reference never terminates otherwise)"};
+    if (!(start_radius > 0.f) || !std::isfinite(start_radius))
+      throw owlmi::ArgError{TKNN_E_ARG, "tknnSolve: start_radius must be finite and > 0"};
+    if (kernel != TKNN_KERNEL_AUTO && kernel != TKNN_KERNEL_LANE && kernel != TKNN_KERNEL_WAVE)
+      throw owlmi::ArgError{TKNN_E_ARG, "tknnSolve: unknown kernel selector"};
+    owlmi::SolveArgs sa;
+    sa.k = k;
+    sa.start_radius = start_radius;
+    sa.max_rounds = max_rounds > 0 ? max_rounds : 64;
+    sa.d_idx = d_idx;
+    sa.d_dist = d_dist;
+    sa.d_isect = d_intersections;
+    sa.d_fb = d_fb;
+    if (info) std::memset(info, 0, sizeof(*info));
+    e->impl.solve(sa, kernel, info, (hipStream_t)stream);
+  });
+}
+
+int tknnExportTree(tknnEngine e, void *nodes, int32_t *rope_node, int32_t *rope_leaf, int32_t *prim_id,
+                   void *stream) {
+  if (!e) {
+    g_last_error = "tknnExportTree: engine is NULL";
+    return TKNN_E_ARG;
+  }
+  return guarded([&] {
+    if (!e->impl.built()) throw owlmi::ArgError{TKNN_E_STATE, "tknnExportTree: call tknnBuild first"};
+    e->impl.tree().download((LbvhNode *)nodes, rope_node, rope_leaf, prim_id, (hipStream_t)stream);
+  });
+}
+
+}  // extern "C"

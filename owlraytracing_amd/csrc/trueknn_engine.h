@@ -1,0 +1,63 @@
+// trueknn_engine.h -- host-side engine object behind include/owlknn.h
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+
+#include "knn_device.h"
+#include "lbvh.h"
+#include "owlknn.h"
+
+namespace owlmi {
+
+struct RoundsExceeded {};
+struct ArgError {
+  int code;
+  std::string what;
+};
+
+struct SolveArgs {
+  int k = 0;
+  float start_radius = 0;
+  int max_rounds = 64;
+  int32_t *d_idx = nullptr;
+  float *d_dist = nullptr;
+  int64_t *d_isect = nullptr;
+  tknnNeigh *d_fb = nullptr;
+};
+
+// smallest register-list capacity instantiated for k, or -1
+int list_capacity_for(int k);
+
+class Engine {
+ public:
+  Engine();
+  ~Engine();
+  Engine(const Engine &) = delete;
+  Engine &operator=(const Engine &) = delete;
+
+  void build(const float *d_xyz, int64_t n, tknnBuildInfo *info, hipStream_t s);
+  void solve(const SolveArgs &sa, int kernel, tknnSolveInfo *info, hipStream_t s);
+  bool built() const { return bvh_.built(); }
+  int64_t size() const { return bvh_.size(); }
+  const Lbvh &tree() const { return bvh_; }
+
+ private:
+  void solve_lane(const SolveArgs &sa, tknnSolveInfo *info, hipStream_t s);
+  void solve_wave(const SolveArgs &sa, tknnSolveInfo *info, hipStream_t s);  // trueknn_wave.hip
+  static bool wave_kernel_available();                                        // trueknn_wave.hip
+
+  int device_ = 0;
+  Lbvh bvh_;
+  uint8_t *done_ = nullptr;
+  int64_t *isect_sorted_ = nullptr;
+  int64_t state_cap_ = 0;
+  unsigned long long *counters_ = nullptr, *h_counters_ = nullptr;
+  void *wave_ws_ = nullptr;
+  size_t wave_ws_bytes_ = 0;
+  int wave_leaf_max_ = 16;  // subtrees of at most this many points are streamed as one range (TKNN_LEAF_MAX)
+  hipEvent_t ev_a_ = nullptr, ev_b_ = nullptr;
+};
+
+}  // namespace owlmi

@@ -1,0 +1,118 @@
+"""Host side of the TrueKNN engine above the C-ABI (include/owlknn.h).
+
+Mirrors what ``samples/s01-trueknn/hostCode.cpp`` does with its command line
+``file n dim start_radius k timefile``: upload points, build the accel (hostCode.cpp:201-206),
+run the radius-doubling solve (hostCode.cpp:285-340) and expose the frameBuffer rows.
+torch is used only to own device memory and the stream.
+"""
+import ctypes
+
+import numpy as np
+
+from . import _lib
+from .datasets import pad_to_3d
+
+NEIGH_BYTES = 24  # GeomTypes.h:22-28
+
+
+class TrueKNN:
+    """One engine on one GPU.  ``points`` may be a numpy array (n,2|3) or a CUDA float32 tensor (n,3)."""
+
+    def __init__(self, device=None):
+        import torch
+
+        self._torch = torch
+        lib = _lib.load()
+        if not torch.cuda.is_available():
+            raise RuntimeError("TrueKNN needs an MI355X: no GPU is visible and there is no CPU fallback")
+        self.device = torch.device("cuda", torch.cuda.current_device() if device is None else device)
+        self._lib = lib
+        self._h = ctypes.c_void_p()
+        with torch.cuda.device(self.device):
+            _lib.check(lib.tknnCreate(ctypes.byref(self._h)))
+        self.n = 0
+        self.build_info = None
+        self.last_info = None
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            self._lib.tknnDestroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _stream(self):
+        return ctypes.c_void_p(self._torch.cuda.current_stream(self.device).cuda_stream)
+
+    def build(self, points):
+        torch = self._torch
+        if isinstance(points, np.ndarray):
+            points = torch.from_numpy(pad_to_3d(points)).to(self.device)
+        if points.dtype != torch.float32 or points.dim() != 2 or points.shape[1] != 3 or not points.is_cuda:
+            raise ValueError("points must be float32 (n,3) on the GPU")
+        points = points.contiguous()
+        info = _lib.BuildInfo()
+        with torch.cuda.device(self.device):
+            _lib.check(self._lib.tknnBuild(self._h, ctypes.c_void_p(points.data_ptr()), points.shape[0],
+                                           ctypes.byref(info), self._stream()))
+        self.n = int(points.shape[0])
+        self.build_info = info.as_dict()
+        return self.build_info
+
+    def solve(self, k, start_radius, kernel=_lib.KERNEL_AUTO, max_rounds=64, want_fb=False,
+              out=None):
+        """Returns dict(idx (n,k) int32, dist (n,k) f32, intersections (n,) int64[, fb (n*k*24,) uint8])
+        as CUDA tensors plus ``info``.  ``out`` may carry preallocated tensors of those names."""
+        torch = self._torch
+        n = self.n
+        out = dict(out or {})
+        with torch.cuda.device(self.device):
+            if n > 0 and k > 0:
+                out.setdefault("idx", torch.empty((n, k), dtype=torch.int32, device=self.device))
+                out.setdefault("dist", torch.empty((n, k), dtype=torch.float32, device=self.device))
+                out.setdefault("intersections", torch.empty((n,), dtype=torch.int64, device=self.device))
+                if want_fb:
+                    out.setdefault("fb", torch.empty((n * k * NEIGH_BYTES,), dtype=torch.uint8, device=self.device))
+            info = _lib.SolveInfo()
+
+            def ptr(name):
+                t = out.get(name)
+                return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+            _lib.check(self._lib.tknnSolve(self._h, int(k), ctypes.c_float(start_radius), int(kernel),
+                                           int(max_rounds), ptr("idx"), ptr("dist"), ptr("intersections"),
+                                           ptr("fb"), ctypes.byref(info), self._stream()))
+        self.last_info = info.as_dict()
+        out["info"] = self.last_info
+        return out
+
+    def export_tree(self):
+        """Host copies of the LBVH for tests: nodes (n-1,8) uint32 view, ropes, prim ids."""
+        torch = self._torch
+        n = self.n
+        nodes = np.zeros((max(n - 1, 1), 8), np.uint32)
+        rope_node = np.zeros(max(n - 1, 1), np.int32)
+        rope_leaf = np.zeros(n, np.int32)
+        prim = np.zeros(n, np.int32)
+        with torch.cuda.device(self.device):
+            _lib.check(self._lib.tknnExportTree(self._h, nodes.ctypes.data, rope_node.ctypes.data,
+                                                rope_leaf.ctypes.data, prim.ctypes.data, self._stream()))
+        return {"nodes": nodes[: max(n - 1, 0)], "rope_node": rope_node[: max(n - 1, 0)],
+                "rope_leaf": rope_leaf, "prim_id": prim}
+
+
+def trueknn(points, k, start_radius, **kw):
+    """One-shot helper: build + solve, results as numpy arrays."""
+    eng = TrueKNN()
+    try:
+        eng.build(points)
+        r = eng.solve(k, start_radius, **kw)
+        res = {name: (v.cpu().numpy() if hasattr(v, "cpu") else v) for name, v in r.items()}
+        res["build_info"] = eng.build_info
+        return res
+    finally:
+        eng.close()

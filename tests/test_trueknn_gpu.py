@@ -1,0 +1,172 @@
+"""Parity of the HIP TrueKNN engine (through the C-ABI) against golden vectors and the CPU checker."""
+import numpy as np
+import pytest
+
+import oracle
+from owlraytracing_amd import _lib, datasets
+
+from conftest import assert_rows_match
+
+pytestmark = pytest.mark.gpu
+
+KERNELS = [_lib.KERNEL_LANE, _lib.KERNEL_WAVE]
+KERNEL_IDS = ["lane", "wave"]
+
+
+def _engine():
+    from owlraytracing_amd.trueknn import TrueKNN
+    return TrueKNN()
+
+
+def _fb_view(fb_bytes, n, k):
+    return fb_bytes.cpu().numpy().view(oracle.NEIGH_DTYPE).reshape(n, k)
+
+
+@pytest.mark.parametrize("kernel", KERNELS, ids=KERNEL_IDS)
+def test_golden_vectors(golden, kernel):
+    eng = _engine()
+    eng.build(golden["xyz"])
+    k = int(golden["k"])
+    r = eng.solve(k, float(golden["start_radius"]), kernel=kernel, want_fb=True)
+    assert r["info"]["kernel_used"] == kernel
+    assert r["info"]["rounds"] == int(golden["rounds"])
+    assert np.float32(r["info"]["final_radius"]) == golden["final_radius"]
+    assert_rows_match(r["idx"].cpu().numpy(), r["dist"].cpu().numpy(), r["intersections"].cpu().numpy(), golden)
+    assert r["info"]["total_intersections"] == int(golden["intersections"].sum())
+    # frameBuffer image = what the reference leaves behind (GeomTypes.h:22-28 records)
+    ref = oracle.trueknn(golden["xyz"], k, float(golden["start_radius"]))
+    fb = _fb_view(r["fb"], len(golden["xyz"]), k)
+    want = ref["fb"].reshape(len(golden["xyz"]), k)
+    for field in ("ind", "dist", "numNeighbors", "intersections"):
+        assert np.array_equal(fb[field], want[field]), field
+    eng.close()
+
+
+@pytest.mark.parametrize("kernel", KERNELS, ids=KERNEL_IDS)
+@pytest.mark.parametrize("n,k,seed", [(100_000, 5, 0), (50_000, 10, 1), (30_000, 16, 2), (20_000, 3, 3)])
+def test_against_oracle_uniform(kernel, n, k, seed):
+    xyz = datasets.uniform3d(n, seed=seed)
+    r0 = datasets.start_radius(n, k)
+    ref = oracle.trueknn(xyz, k, r0)
+    eng = _engine()
+    eng.build(xyz)
+    r = eng.solve(k, r0, kernel=kernel)
+    assert r["info"]["rounds"] == ref["rounds"]
+    assert np.array_equal(r["idx"].cpu().numpy(), ref["idx"])
+    assert np.array_equal(r["dist"].cpu().numpy().view(np.int32), ref["dist"].view(np.int32))
+    assert np.array_equal(r["intersections"].cpu().numpy(), ref["intersections"])
+    eng.close()
+
+
+@pytest.mark.parametrize("kernel", KERNELS, ids=KERNEL_IDS)
+def test_against_oracle_clustered_and_duplicates(kernel):
+    xyz = datasets.gaussian_mixture3d(60_000, components=16, sigma=0.01, seed=5)
+    xyz[::11] = xyz[3::11][: len(xyz[::11])]  # exact duplicates: ties at distance 0
+    ref = oracle.trueknn(xyz, 8, 0.002)
+    eng = _engine()
+    eng.build(xyz)
+    r = eng.solve(8, 0.002, kernel=kernel)
+    assert r["info"]["rounds"] == ref["rounds"]
+    assert np.array_equal(r["idx"].cpu().numpy(), ref["idx"])
+    assert np.array_equal(r["dist"].cpu().numpy(), ref["dist"])
+    assert np.array_equal(r["intersections"].cpu().numpy(), ref["intersections"])
+    eng.close()
+
+
+@pytest.mark.parametrize("kernel", KERNELS, ids=KERNEL_IDS)
+def test_planar_input_and_heavy_tail(kernel):
+    xy = datasets.taxi_like2d(40_000, components=32, seed=2)
+    xyz = datasets.pad_to_3d(xy)
+    ref = oracle.trueknn(xyz, 6, 0.0005)
+    eng = _engine()
+    eng.build(xy)  # 2-D input is padded with z = 0 like hostCode.cpp:115-118
+    r = eng.solve(6, 0.0005, kernel=kernel)
+    assert r["info"]["rounds"] == ref["rounds"]
+    assert np.array_equal(r["idx"].cpu().numpy(), ref["idx"])
+    assert np.array_equal(r["dist"].cpu().numpy(), ref["dist"])
+    assert np.array_equal(r["intersections"].cpu().numpy(), ref["intersections"])
+    eng.close()
+
+
+def test_lbvh_invariants():
+    xyz = datasets.gaussian_mixture3d(20_000, components=8, sigma=0.02, seed=9)
+    xyz[100:200] = xyz[0]  # identical Morton codes: index tie-break in the radix tree
+    eng = _engine()
+    eng.build(xyz)
+    t = eng.export_tree()
+    n = len(xyz)
+    nodes = t["nodes"]
+    lo = nodes[:, 0:3].view(np.float32)
+    hi = nodes[:, 4:7].view(np.float32)
+    split = nodes[:, 3].view(np.int32)
+    other = nodes[:, 7].view(np.int32)
+    prim = t["prim_id"]
+    assert sorted(prim.tolist()) == list(range(n))
+    pts = xyz[prim]
+    i = np.arange(n - 1)
+    first, last = np.minimum(i, other), np.maximum(i, other)
+    assert first[0] == 0 and last[0] == n - 1
+    assert np.all((split >= first) & (split < last))
+    # boxes are exactly the bounds of the covered sorted range
+    for node in list(range(0, 200)) + list(range(n - 200, n - 1)):
+        seg = pts[first[node]:last[node] + 1]
+        assert np.array_equal(lo[node], seg.min(0)) and np.array_equal(hi[node], seg.max(0))
+    # a rope-guided walk that never descends visits the root only; one that always descends
+    # visits every leaf exactly once, in sorted order
+    ref, seen, steps = 0, [], 0
+    while ref != np.int32(-2**31) and steps < 3 * n:
+        steps += 1
+        if ref >= 0:
+            ref = (~split[ref]) if first[ref] == split[ref] else split[ref]
+        else:
+            seen.append(~ref)
+            ref = t["rope_leaf"][~ref]
+    assert seen == list(range(n))
+    assert t["rope_node"][0] == np.int32(-2**31)
+    eng.close()
+
+
+def test_argument_errors_are_reported_not_hidden():
+    eng = _engine()
+    with pytest.raises(_lib.TknnError) as e:
+        eng.solve(3, 0.1)
+    assert e.value.code == -3  # TKNN_E_STATE
+    xyz = datasets.uniform3d(10, seed=0)
+    eng.build(xyz)
+    for k, r0, code in ((10, 0.1, -1), (0, 0.1, -1), (3, 0.0, -1), (3, float("inf"), -1), (65, 0.1, -5)):
+        with pytest.raises(_lib.TknnError) as e:
+            eng.solve(k, r0)
+        assert e.value.code == code
+    # far-apart duplicates of fewer than k+1 distinct places still terminate; max_rounds is honoured
+    with pytest.raises(_lib.TknnError) as e:
+        eng.solve(3, 1e-30, max_rounds=3)
+    assert e.value.code == -4
+    eng.close()
+
+
+@pytest.mark.parametrize("kernel", KERNELS, ids=KERNEL_IDS)
+def test_full_size_properties_c2(kernel):
+    """BASELINE config 2 (10 M points, k=10): size-independent properties + sampled oracle rows."""
+    n, k = 10_000_000, 10
+    xyz = datasets.uniform3d(n, seed=0)
+    r0 = datasets.start_radius(n, k)
+    eng = _engine()
+    eng.build(xyz)
+    r = eng.solve(k, r0, kernel=kernel)
+    idx, dist, isect = r["idx"], r["dist"], r["intersections"]
+    import torch
+    ar = torch.arange(n, device=idx.device, dtype=torch.int32)[:, None]
+    assert bool((idx != ar).all()) and bool((idx >= 0).all()) and bool((idx < n).all())
+    assert bool((dist[:, 1:] >= dist[:, :-1]).all())
+    assert int(isect.sum()) == r["info"]["total_intersections"]
+    # checksum of checksums: recompute every distance from the indices on the GPU in fp64
+    pts = torch.from_numpy(xyz).to(idx.device)
+    d64 = (pts[idx.long()].double() - pts[:, None, :].double()).norm(dim=2)
+    assert float((d64 - dist.double()).abs().max()) < 1e-6
+    # sampled rows against the CPU checker (bit-exact)
+    q = np.arange(0, n, 5003, dtype=np.int32)
+    ref = oracle.trueknn(xyz, k, r0, query_ids=q)
+    assert np.array_equal(idx[q.astype(np.int64)].cpu().numpy(), ref["idx"][q])
+    assert np.array_equal(dist[q.astype(np.int64)].cpu().numpy(), ref["dist"][q])
+    assert np.array_equal(isect[q.astype(np.int64)].cpu().numpy(), ref["intersections"][q])
+    eng.close()
