@@ -117,6 +117,12 @@ TKNN_API int tknnSolve(tknnEngine e, int k, float start_radius, int kernel, int 
 TKNN_API int tknnExportTree(tknnEngine e, void *nodes, int32_t *rope_node, int32_t *rope_leaf,
                             int32_t *prim_id, void *stream);
 
+/* Test hook for the wave kernel's candidate test.  For each pair (q[i], r[i]) writes lo[i], hi[i]
+ * such that, for every fp32 c,   lo <= c <= hi   <=>   fl(c - r) <= q <= fl(c + r)
+ * (the box the bounds program of deviceCode.cu:38-56 writes, tested against the query point). */
+TKNN_API int tknnDebugThresholds(const float *d_q, const float *d_r, int64_t n, float *d_lo,
+                                 float *d_hi, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -58,6 +58,8 @@ SIGNATURES = {
                                  ctypes.c_void_p, ctypes.POINTER(SolveInfo), ctypes.c_void_p]),
     "tknnExportTree": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                                       ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
+    "tknnDebugThresholds": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64,
+                                           ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
 }
 
 _lib = None

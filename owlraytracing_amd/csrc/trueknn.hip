@@ -365,4 +365,15 @@ int tknnExportTree(tknnEngine e, void *nodes, int32_t *rope_node, int32_t *rope_
   });
 }
 
+int tknnDebugThresholds(const float *d_q, const float *d_r, int64_t n, float *d_lo, float *d_hi, void *stream) {
+  if (!d_q || !d_r || !d_lo || !d_hi || n < 0) {
+    g_last_error = "tknnDebugThresholds: null pointer";
+    return TKNN_E_ARG;
+  }
+  return guarded([&] {
+    owlmi::debug_thresholds(d_q, d_r, n, d_lo, d_hi, (hipStream_t)stream);
+    OWLMI_HIP(hipStreamSynchronize((hipStream_t)stream));
+  });
+}
+
 }  // extern "C"

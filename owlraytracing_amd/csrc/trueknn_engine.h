@@ -30,6 +30,9 @@ struct SolveArgs {
 // smallest register-list capacity instantiated for k, or -1
 int list_capacity_for(int k);
 
+// test hook: the wave kernel's exact candidate thresholds for (q, r) pairs (trueknn_wave.hip)
+void debug_thresholds(const float *d_q, const float *d_r, int64_t n, float *d_lo, float *d_hi, hipStream_t s);
+
 class Engine {
  public:
   Engine();

@@ -11,9 +11,10 @@
 //     and box-tested per step (one per lane) against the union of the packet's thresholds,
 //     survivors' children pushed with ballot + prefix-count compaction;
 //   * subtrees of <= leaf_max points are "leaf ranges": contiguous runs of the Morton-sorted point
-//     array.  A range is refined against the 64 individual query boxes (ballot) and then streamed
-//     through SCALAR loads (the candidate is wave-uniform), each lane testing it against its own
-//     thresholds;
+//     array.  A range is refined against the 64 individual query boxes (ballot), loaded with one
+//     coalesced 16 B/lane access (lane l holds its l-th point) and broadcast point by point with
+//     v_readlane, each lane testing the candidate against its own thresholds -- the candidate
+//     loop touches no memory;
 //   * survivors that could enter the lane's k-list are queued in a small per-lane LDS queue and
 //     merged into the register-resident sorted list in bursts, so the long insertion sequence runs
 //     with most lanes busy instead of once per candidate.
@@ -31,11 +32,11 @@ namespace owlmi {
 namespace {
 
 constexpr int kWaveBlock = 256;          // 4 independent waves per workgroup
-constexpr int kStackCap = 512;           // node references per wave (LDS)
+constexpr int kStackCap = 1024;          // node references per wave (LDS)
+constexpr int kStackReserve = 160;       // slots kept for depth-first descent (tree depth <= 63 + 32 + 1)
 constexpr int kQueueDepth = 8;           // pending k-list candidates per lane (LDS)
-constexpr int kWaveLds = kStackCap * 4 + kQueueDepth * 64 * 8;  // 6 KiB per wave
+constexpr int kWaveLds = kStackCap * 4 + kQueueDepth * 64 * 8;  // 8 KiB per wave
 
-#define OWLMI_AS4 __attribute__((address_space(4)))
 
 struct WaveArgs {
   LbvhView bvh;
@@ -59,48 +60,85 @@ __device__ __forceinline__ void wave_lds_sync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-__device__ __forceinline__ float next_up(float x) {
-  if (!(x < INFINITY)) return x;  // +inf, NaN
-  if (x == 0.f) return __uint_as_float(1u);
-  uint32_t b = __float_as_uint(x);
-  return __uint_as_float(x > 0.f ? b + 1 : b - 1);
+// fp32 <-> uint32 keys that ascend with the float order (-inf .. -0, +0 .. +inf)
+__device__ __forceinline__ uint32_t f_ord(float f) {
+  uint32_t b = __float_as_uint(f);
+  return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
 }
-__device__ __forceinline__ float next_down(float x) {
-  if (!(x > -INFINITY)) return x;
-  if (x == 0.f) return __uint_as_float(0x80000001u);
-  uint32_t b = __float_as_uint(x);
-  return __uint_as_float(x > 0.f ? b - 1 : b + 1);
+__device__ __forceinline__ float f_unord(uint32_t u) {
+  return __uint_as_float((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u);
+}
+#define OWLMI_ORD_NEG_INF 0x007fffffu /* f_ord(-inf) */
+#define OWLMI_ORD_POS_INF 0xff800000u /* f_ord(+inf) */
+
+// Smallest float c (as an ordered key) for which the monotone predicate P holds, searched from
+// `guess`: gallop away from the guess in doubling strides, then bisect.  P must be false at -inf
+// side / true at +inf side of some boundary; the result is clamped to [-inf, +inf].  The guess is
+// normally within a few ulps, but NOT near zero or across binades (q ~ r), where a linear ulp walk
+// would take millions of steps -- hence the search on the key line.
+template <typename P>
+__device__ __forceinline__ uint32_t first_true_key(P pred, float guess) {
+  uint32_t u = f_ord(guess);
+  u = u < OWLMI_ORD_NEG_INF ? OWLMI_ORD_NEG_INF : (u > OWLMI_ORD_POS_INF ? OWLMI_ORD_POS_INF : u);
+  uint32_t lo, hi;  // invariant at the end: pred(hi) true (or hi == +inf), pred(lo) false (or lo == -inf)
+  if (pred(f_unord(u))) {
+    hi = u;
+    uint32_t step = 1;
+    for (;;) {
+      uint32_t room = hi - OWLMI_ORD_NEG_INF;
+      if (room == 0) return hi;
+      uint32_t s = step < room ? step : room;
+      uint32_t t = hi - s;
+      if (t != OWLMI_ORD_NEG_INF && pred(f_unord(t))) {
+        hi = t;
+        step <<= 1;
+      } else if (t == OWLMI_ORD_NEG_INF && pred(f_unord(t))) {
+        return t;
+      } else {
+        lo = t;
+        break;
+      }
+    }
+  } else {
+    lo = u;
+    uint32_t step = 1;
+    for (;;) {
+      uint32_t room = OWLMI_ORD_POS_INF - lo;
+      if (room == 0) return OWLMI_ORD_POS_INF + 1u;  // nothing satisfies P, not even +inf
+      uint32_t s = step < room ? step : room;
+      uint32_t t = lo + s;
+      if (pred(f_unord(t))) {
+        hi = t;
+        break;
+      }
+      lo = t;
+      step <<= 1;
+    }
+  }
+  while (hi - lo > 1u) {
+    uint32_t mid = lo + ((hi - lo) >> 1);
+    if (pred(f_unord(mid)))
+      hi = mid;
+    else
+      lo = mid;
+  }
+  return hi;
 }
 
-// largest c with fl(c - r) <= q   (so that  fl(c - r) <= q  <=>  c <= thr_hi(q, r))
-__device__ __forceinline__ float thr_hi(float q, float r) {
-#pragma clang fp contract(off)
-  float c = q + r;
-  if (!(c == c)) return -INFINITY;
-  for (;;) {
-    float u = next_up(c);
-    if (u > c && u - r <= q)
-      c = u;
-    else
-      break;
-  }
-  while (!(c - r <= q) && c > -INFINITY) c = next_down(c);
-  return c;
-}
-// smallest c with q <= fl(c + r)
+// smallest c with q <= fl(c + r)      (q <= fl(c + r)  <=>  c >= thr_lo(q, r))
 __device__ __forceinline__ float thr_lo(float q, float r) {
 #pragma clang fp contract(off)
-  float c = q - r;
-  if (!(c == c)) return INFINITY;
-  for (;;) {
-    float d = next_down(c);
-    if (d < c && q <= d + r)
-      c = d;
-    else
-      break;
-  }
-  while (!(q <= c + r) && c < INFINITY) c = next_up(c);
-  return c;
+  if (!(q == q)) return INFINITY;
+  uint32_t key = first_true_key([=](float c) { return q <= c + r; }, q - r);
+  return key > OWLMI_ORD_POS_INF ? INFINITY : f_unord(key);
+}
+// largest c with fl(c - r) <= q       (fl(c - r) <= q  <=>  c <= thr_hi(q, r))
+__device__ __forceinline__ float thr_hi(float q, float r) {
+#pragma clang fp contract(off)
+  if (!(q == q)) return -INFINITY;
+  uint32_t key = first_true_key([=](float c) { return !(c - r <= q); }, q + r);  // first c that fails
+  if (key <= OWLMI_ORD_NEG_INF) return -INFINITY;
+  return f_unord(key - 1u);
 }
 
 __device__ __forceinline__ float wave_min(float v) {
@@ -188,7 +226,6 @@ __global__ void __launch_bounds__(kWaveBlock) wave_packet_kernel(WaveArgs a) {
   int32_t *stack = (int32_t *)(smem + wid * kWaveLds);
   uint64_t *queue = (uint64_t *)(smem + wid * kWaveLds + kStackCap * 4);
   const LbvhView &bvh = a.bvh;
-  const OWLMI_AS4 LbvhPoint *cpts = (const OWLMI_AS4 LbvhPoint *)bvh.points;
 
   unsigned long long my_isect_sum = 0, wave_node_tests = 0, wave_point_tests = 0;
   int wave_levels = 0, wave_err = 0;
@@ -229,13 +266,42 @@ __global__ void __launch_bounds__(kWaveBlock) wave_packet_kernel(WaveArgs a) {
       st.cnt = 0;
       st.others = 0;
 
+      // One leaf range is always "pending" in registers (lane l holds its l-th point, loaded with
+      // one coalesced 16 B/lane access); its points are broadcast with v_readlane, so the candidate
+      // loop touches no memory.  The next range's load is issued before the pending one is
+      // processed, and the node loads of the next pop are issued before the last range of the
+      // previous pop is processed, so HBM/L2 latency hides behind the compare/insert work.
+      LbvhPoint pend = {0.f, 0.f, 0.f, -1};
+      int pend_count = 0;
+      auto process_pending = [&]() {
+        for (int j = 0; j < pend_count; j++) {
+          const float px = bcast_f(pend.x, j), py = bcast_f(pend.y, j), pz = bcast_f(pend.z, j);
+          const int32_t pid = __builtin_amdgcn_readlane(pend.id, j);
+          const bool in = (lo_x <= px) & (px <= hi_x) & (lo_y <= py) & (py <= hi_y) & (lo_z <= pz) & (pz <= hi_z);
+          const bool other = in & (pid != q.id);
+          st.cnt += in ? 1u : 0u;
+          st.others += other ? 1u : 0u;
+          const float d2 = knn_dist2(px, py, pz, q.x, q.y, q.z);
+          if (other & (d2 <= st.tau2)) {
+            queue[st.qpos * 64 + lane] = ((uint64_t)__float_as_uint(d2) << 32) | (uint32_t)pid;
+            st.qpos++;
+          }
+          if (__ballot(st.qpos == kQueueDepth) != 0ull) flush_queue<K>(st, queue, lane);
+        }
+        pend_count = 0;
+      };
+
       int sp = 1;
       if (lane == 0) stack[0] = bvh.root;
       wave_lds_sync();
 
       while (sp > 0) {
-        int w = min(64, min(sp, kStackCap - sp));
-        if (w <= 0) {  // cannot make room for children: report, the host re-solves with the lane kernel
+        // Pop width: up to 64 nodes while the stack has room for all their children; as it fills,
+        // narrow down to single-node (depth-first) steps, which need at most one slot per tree
+        // level still below -- kStackReserve covers the deepest possible radix tree.
+        const int room = kStackCap - sp;
+        int w = min(64, min(sp, max(1, room - kStackReserve)));
+        if (room < 2) {  // not even one node's children fit: report, the host re-solves with the lane kernel
           wave_err |= 2;
           break;
         }
@@ -244,13 +310,23 @@ __global__ void __launch_bounds__(kWaveBlock) wave_packet_kernel(WaveArgs a) {
         sp -= w;
         wave_node_tests += (unsigned)w;
 
+        // issue my node's loads, then overlap them with the pending range
+        LbvhNode nd = {{0.f, 0.f, 0.f}, 0, {0.f, 0.f, 0.f}, 0};
+        LbvhPoint np = {0.f, 0.f, 0.f, -1};
+        if (lane < w) {
+          if (ref >= 0)
+            nd = bvh.nodes[ref];
+          else
+            np = bvh.points[~ref];
+        }
+        if (pend_count) process_pending();
+
         // classify my node: box over centres + covered range
         float n_lo_x = 0, n_lo_y = 0, n_lo_z = 0, n_hi_x = 0, n_hi_y = 0, n_hi_z = 0;
         int32_t first = 0, count = 0, left = LBVH_END, right = LBVH_END;
         bool overlap = false;
         if (lane < w) {
           if (ref >= 0) {
-            const LbvhNode nd = bvh.nodes[ref];
             n_lo_x = nd.lo[0];
             n_lo_y = nd.lo[1];
             n_lo_z = nd.lo[2];
@@ -262,10 +338,9 @@ __global__ void __launch_bounds__(kWaveBlock) wave_packet_kernel(WaveArgs a) {
             left = lbvh_left_ref(ref, nd);
             right = lbvh_right_ref(ref, nd);
           } else {
-            const LbvhPoint p = bvh.points[~ref];
-            n_lo_x = n_hi_x = p.x;
-            n_lo_y = n_hi_y = p.y;
-            n_lo_z = n_hi_z = p.z;
+            n_lo_x = n_hi_x = np.x;
+            n_lo_y = n_hi_y = np.y;
+            n_lo_z = n_hi_z = np.z;
             first = ~ref;
             count = 1;
           }
@@ -286,36 +361,28 @@ __global__ void __launch_bounds__(kWaveBlock) wave_packet_kernel(WaveArgs a) {
         sp += 2 * __popcll(emask);
         wave_lds_sync();
 
-        // leaf ranges: stream their points past all 64 query boxes
+        // leaf ranges: refine against the 64 individual query boxes, then stream the survivors
         unsigned long long rmask = __ballot(is_range);
         while (rmask) {
           const int src = __ffsll((long long)rmask) - 1;
           rmask &= rmask - 1;
           const float b_lo_x = bcast_f(n_lo_x, src), b_lo_y = bcast_f(n_lo_y, src), b_lo_z = bcast_f(n_lo_z, src);
           const float b_hi_x = bcast_f(n_hi_x, src), b_hi_y = bcast_f(n_hi_y, src), b_hi_z = bcast_f(n_hi_z, src);
-          const bool mine = active & (b_lo_x <= hi_x) & (b_hi_x >= lo_x) & (b_lo_y <= hi_y) & (b_hi_y >= lo_y) &
+          const bool mine = (b_lo_x <= hi_x) & (b_hi_x >= lo_x) & (b_lo_y <= hi_y) & (b_hi_y >= lo_y) &
                             (b_lo_z <= hi_z) & (b_hi_z >= lo_z);
           const unsigned long long takers = __ballot(mine);
           if (takers == 0ull) continue;
           const int r_first = __builtin_amdgcn_readlane(first, src);
           const int r_count = __builtin_amdgcn_readlane(count, src);
           wave_point_tests += (unsigned long long)r_count * (unsigned)__popcll(takers);
-          for (int j = 0; j < r_count; j++) {
-            const LbvhPoint p = cpts[r_first + j];  // wave-uniform -> scalar load
-            const bool in = active & (lo_x <= p.x) & (p.x <= hi_x) & (lo_y <= p.y) & (p.y <= hi_y) &
-                            (lo_z <= p.z) & (p.z <= hi_z);
-            const bool other = in & (p.id != q.id);
-            st.cnt += in ? 1u : 0u;
-            st.others += other ? 1u : 0u;
-            const float d2 = knn_dist2(p.x, p.y, p.z, q.x, q.y, q.z);
-            if (other & (d2 <= st.tau2)) {
-              queue[st.qpos * 64 + lane] = ((uint64_t)__float_as_uint(d2) << 32) | (uint32_t)p.id;
-              st.qpos++;
-            }
-            if (__ballot(st.qpos == kQueueDepth) != 0ull) flush_queue<K>(st, queue, lane);
-          }
+          LbvhPoint nxt = {0.f, 0.f, 0.f, -1};
+          if (lane < r_count) nxt = bvh.points[r_first + lane];
+          if (pend_count) process_pending();
+          pend = nxt;
+          pend_count = r_count;
         }
       }
+      if (pend_count) process_pending();
       flush_queue<K>(st, queue, lane);
 
       bool finished = false;
@@ -364,7 +431,21 @@ int max_blocks_per_cu() {
   return std::max(1, nb);
 }
 
+__global__ void thresholds_kernel(const float *__restrict__ q, const float *__restrict__ r, int64_t n,
+                                  float *__restrict__ lo, float *__restrict__ hi) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  lo[i] = thr_lo(q[i], r[i]);
+  hi[i] = thr_hi(q[i], r[i]);
+}
+
 }  // namespace
+
+void debug_thresholds(const float *d_q, const float *d_r, int64_t n, float *d_lo, float *d_hi, hipStream_t s) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(thresholds_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, d_q, d_r, n, d_lo, d_hi);
+  OWLMI_HIP(hipGetLastError());
+}
 
 bool Engine::wave_kernel_available() { return true; }
 

@@ -1,0 +1,46 @@
+#!/usr/bin/env python3
+"""Developer timing loop: both kernels, several sizes.  Not the contract bench (see bench.py)."""
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+
+from owlraytracing_amd import _lib, datasets  # noqa: E402
+from owlraytracing_amd.trueknn import TrueKNN  # noqa: E402
+
+
+def main():
+    sizes = [int(s) for s in (sys.argv[1] if len(sys.argv) > 1 else "1000000,10000000").split(",")]
+    k = int(sys.argv[2]) if len(sys.argv) > 2 else 10
+    kernels = [int(x) for x in (sys.argv[3] if len(sys.argv) > 3 else "1,2").split(",")]
+    reps = int(sys.argv[4]) if len(sys.argv) > 4 else 3
+    for n in sizes:
+        xyz = torch.from_numpy(datasets.uniform3d(n, seed=0)).cuda()
+        r0 = datasets.start_radius(n, k)
+        eng = TrueKNN()
+        bi = eng.build(xyz)
+        bi = eng.build(xyz)
+        print("n=%d k=%d r0=%.5g build_ms=%.2f tree_MB=%.0f" % (n, k, r0, bi["build_ms"], bi["device_bytes"] / 1e6), flush=True)
+        out = None
+        for kern in kernels:
+            best = None
+            for _ in range(reps):
+                torch.cuda.synchronize()
+                t = time.perf_counter()
+                r = eng.solve(k, r0, kernel=kern, out=out)
+                torch.cuda.synchronize()
+                wall = (time.perf_counter() - t) * 1e3
+                out = {kk: v for kk, v in r.items() if kk != "info"}
+                i = r["info"]
+                best = wall if best is None else min(best, wall)
+            print("  kernel=%d wall_ms=%.2f dev_ms=%.2f rounds=%d isect/q=%.1f node_tests=%.3g point_tests=%.3g q/s=%.3g" % (
+                kern, best, i["solve_ms"], i["rounds"], i["total_intersections"] / n, i["node_tests"], i["point_tests"], n / best * 1e3), flush=True)
+        eng.close()
+
+
+if __name__ == "__main__":
+    main()

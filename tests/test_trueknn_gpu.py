@@ -88,6 +88,41 @@ def test_planar_input_and_heavy_tail(kernel):
     eng.close()
 
 
+def test_candidate_thresholds_equal_the_literal_box_test():
+    """lo <= c <= hi must select exactly the c with fl(c - r) <= q <= fl(c + r), including near
+    zero, across binades and at exact box boundaries (where a per-ulp walk would take forever)."""
+    import ctypes
+    import torch
+    rng = np.random.default_rng(0)
+    q = np.concatenate([
+        rng.random(4000, dtype=np.float32), np.float32([0, 0.125, 0.25, 1.375, 1e-30, -1e-30, 0.005, 0.0050001]),
+        (rng.random(2000, dtype=np.float32) - 0.5) * np.float32(1e-3), rng.normal(0, 100, 1000).astype(np.float32)])
+    r = np.concatenate([
+        np.full(4000, 0.005, np.float32), np.float32([0.125, 0.125, 0.125, 0.125, 0.005, 0.005, 0.005, 0.005]),
+        np.exp(rng.uniform(np.log(1e-6), np.log(10), 3000)).astype(np.float32)])
+    # make some q exactly r-aligned so that q - r == 0 / boundaries coincide
+    q[:500] = (np.arange(500) % 7).astype(np.float32) * r[:500]
+    tq, tr = torch.from_numpy(q).cuda(), torch.from_numpy(r).cuda()
+    lo, hi = torch.empty_like(tq), torch.empty_like(tq)
+    _lib.check(_lib.load().tknnDebugThresholds(
+        ctypes.c_void_p(tq.data_ptr()), ctypes.c_void_p(tr.data_ptr()), len(q),
+        ctypes.c_void_p(lo.data_ptr()), ctypes.c_void_p(hi.data_ptr()), None))
+    lo, hi = lo.cpu().numpy(), hi.cpu().numpy()
+    assert np.all(lo <= hi)
+    def literal(c):
+        return ((c - r).astype(np.float32) <= q) & (q <= (c + r).astype(np.float32))
+    for base in (lo, hi):
+        c = base.copy()
+        for _ in range(3):  # walk a few ulps outward and inward around both thresholds
+            for cand in (c, np.nextafter(c, np.float32(-np.inf)), np.nextafter(c, np.float32(np.inf))):
+                assert np.array_equal((lo <= cand) & (cand <= hi), literal(cand))
+            c = np.nextafter(c, np.float32(np.inf) if base is hi else np.float32(-np.inf))
+    # interior and far-away points
+    for cand in (q, q + r * np.float32(0.5), q - r * np.float32(3), q + r * np.float32(3)):
+        cand = cand.astype(np.float32)
+        assert np.array_equal((lo <= cand) & (cand <= hi), literal(cand))
+
+
 def test_lbvh_invariants():
     xyz = datasets.gaussian_mixture3d(20_000, components=8, sigma=0.02, seed=9)
     xyz[100:200] = xyz[0]  # identical Morton codes: index tie-break in the radix tree
