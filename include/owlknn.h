@@ -73,6 +73,7 @@ typedef struct {
   int64_t total_intersections; /* sum of Neigh.intersections = intersection-program calls         */
   int64_t node_tests;          /* box tests against BVH nodes (wave kernel: per packet)           */
   int64_t point_tests;         /* exact point-in-box tests executed (>= total_intersections)      */
+  int64_t total_active_rounds; /* sum over queries of the rounds in which the query traced a ray  */
   float solve_ms;              /* device time of the traversal launches, HIP events on `stream`   */
   float dominant_kernel_ms;    /* average duration of one launch of the dominant kernel           */
   int32_t dominant_kernel_launches;

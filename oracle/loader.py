@@ -52,6 +52,7 @@ def _load():
             ctypes.c_uint64, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_void_p,
             ctypes.c_void_p,
         ]
+        lib.tkref_last_query_seconds.restype = ctypes.c_double
         lib.tkref_bruteforce.restype = ctypes.c_int
         lib.tkref_bruteforce.argtypes = [
             ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_void_p, ctypes.c_int64,
@@ -115,6 +116,7 @@ def trueknn(xyz, k, start_radius, order=ORDER_ASCENDING, seed=0, query_ids=None,
         "num_neighbors": rows["numNeighbors"][:, 0],
         "rounds": rc,
         "final_radius": float(fr.value),
+        "query_seconds": float(lib.tkref_last_query_seconds()),
     }
 
 

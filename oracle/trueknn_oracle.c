@@ -47,9 +47,21 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 #ifdef _OPENMP
 #include <omp.h>
 #endif
+
+/* wall time the last tkref_trueknn call spent in its query loops (candidate enumeration + the
+ * intersection program), excluding the per-round grid construction over all points, which a
+ * full run amortises over all n queries; read by bench.py's cpu_baseline leg */
+static double g_query_seconds = 0.0;
+double tkref_last_query_seconds(void) { return g_query_seconds; }
+static double tk_now(void) {
+  struct timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
 
 /* GeomTypes.h:22-28 -- 4+4+4(+4 pad)+8 = 24 bytes */
 typedef struct {
@@ -279,12 +291,14 @@ int tkref_trueknn(const float *xyz, int64_t n, int k, float start_radius, int or
   if (!query_ids) n_queries = n;
   float radius = start_radius;
   int rounds = 0;
+  g_query_seconds = 0.0;
   for (;;) {
     if (rounds >= max_rounds) return -3;
     rounds++;
     tk_grid g;
     if (tk_grid_build(&g, xyz, n, fabs((double)radius) * 1.0001 + 1e-30)) return -2;
     int failed = 0;
+    double t_start = tk_now();
 #pragma omp parallel
     {
       int32_t *buf = NULL;
@@ -304,6 +318,7 @@ int tkref_trueknn(const float *xyz, int64_t n, int k, float start_radius, int or
       }
       free(buf);
     }
+    g_query_seconds += tk_now() - t_start;
     tk_grid_free(&g);
     if (failed) return -2;
     int again = 0; /* hostCode.cpp:310-330 */

@@ -27,6 +27,7 @@ class SolveInfo(ctypes.Structure):
         ("total_intersections", ctypes.c_int64),
         ("node_tests", ctypes.c_int64),
         ("point_tests", ctypes.c_int64),
+        ("total_active_rounds", ctypes.c_int64),
         ("solve_ms", ctypes.c_float),
         ("dominant_kernel_ms", ctypes.c_float),
         ("dominant_kernel_launches", ctypes.c_int32),

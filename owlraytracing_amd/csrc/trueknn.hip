@@ -30,7 +30,7 @@ struct LaneRoundArgs {
   float *out_dist;         // n*k (may be null)
   int64_t *out_isect;      // n (may be null)
   tknnNeigh *out_fb;       // n*k (may be null)
-  unsigned long long *counters;  // [0] unfinished, [1] node tests, [2] point tests, [3] sum isect
+  unsigned long long *counters;  // [0] unfinished, [1] node tests, [2] point tests, [3] sum isect, [4] active lanes
 };
 
 template <int K>
@@ -113,6 +113,7 @@ __global__ void __launch_bounds__(kLaneBlock) lane_round_kernel(LaneRoundArgs a)
   }
   // wave-aggregated counters (all 64 lanes are here)
   unsigned long long unfinished = __popcll(__ballot(active && !finished));
+  unsigned long long traced = __popcll(__ballot(active));
   unsigned long long nt = node_tests, pt = point_tests, si = finished ? (unsigned long long)isect : 0ull;
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) {
@@ -125,6 +126,7 @@ __global__ void __launch_bounds__(kLaneBlock) lane_round_kernel(LaneRoundArgs a)
     atomicAdd(&a.counters[1], nt);
     atomicAdd(&a.counters[2], pt);
     if (si) atomicAdd(&a.counters[3], si);
+    if (traced) atomicAdd(&a.counters[4], traced);
   }
 }
 
@@ -227,7 +229,7 @@ void Engine::solve_lane(const SolveArgs &sa, tknnSolveInfo *info, hipStream_t s)
     OWLMI_HIP(hipGetLastError());
     OWLMI_HIP(hipEventRecord(ev_b_, s));
     // hostCode.cpp:310-330: the host decides about another round from the result state
-    OWLMI_HIP(hipMemcpyAsync(h_counters_, counters_, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+    OWLMI_HIP(hipMemcpyAsync(h_counters_, counters_, 5 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
     OWLMI_HIP(hipStreamSynchronize(s));
     float ms = 0;
     OWLMI_HIP(hipEventElapsedTime(&ms, ev_a_, ev_b_));
@@ -241,6 +243,7 @@ void Engine::solve_lane(const SolveArgs &sa, tknnSolveInfo *info, hipStream_t s)
     info->node_tests = (int64_t)h_counters_[1];
     info->point_tests = (int64_t)h_counters_[2];
     info->total_intersections = (int64_t)h_counters_[3];
+    info->total_active_rounds = (int64_t)h_counters_[4];
     info->solve_ms = total_ms;
     info->dominant_kernel_ms = total_ms / rounds;
     info->dominant_kernel_launches = rounds;

@@ -50,7 +50,7 @@ struct WaveArgs {
   int64_t *out_isect;
   tknnNeigh *out_fb;
   // [0] packet counter  [1] max level+1  [2] node tests  [3] point tests  [4] sum intersections
-  // [5] error flags (1: max_rounds reached, 2: stack overflow)
+  // [5] error flags (1: max_rounds reached, 2: stack overflow)  [6] sum over queries of levels run
   unsigned long long *counters;
 };
 
@@ -227,7 +227,7 @@ __global__ void __launch_bounds__(kWaveBlock) wave_packet_kernel(WaveArgs a) {
   uint64_t *queue = (uint64_t *)(smem + wid * kWaveLds + kStackCap * 4);
   const LbvhView &bvh = a.bvh;
 
-  unsigned long long my_isect_sum = 0, wave_node_tests = 0, wave_point_tests = 0;
+  unsigned long long my_isect_sum = 0, my_levels = 0, wave_node_tests = 0, wave_point_tests = 0;
   int wave_levels = 0, wave_err = 0;
 
   for (;;) {
@@ -387,6 +387,7 @@ __global__ void __launch_bounds__(kWaveBlock) wave_packet_kernel(WaveArgs a) {
 
       bool finished = false;
       if (active) {
+        my_levels++;
         isect += st.cnt;
         finished = st.others >= (uint32_t)a.k;
         if (finished) {
@@ -408,11 +409,13 @@ __global__ void __launch_bounds__(kWaveBlock) wave_packet_kernel(WaveArgs a) {
 
   // once per wave lifetime
   const unsigned long long isum = wave_sum(my_isect_sum);
+  const unsigned long long lsum = wave_sum(my_levels);
   if (lane == 0) {
     atomicMax(&a.counters[1], (unsigned long long)wave_levels);
     atomicAdd(&a.counters[2], wave_node_tests);
     atomicAdd(&a.counters[3], wave_point_tests);
     atomicAdd(&a.counters[4], isum);
+    atomicAdd(&a.counters[6], lsum);
     if (wave_err) atomicOr(&a.counters[5], (unsigned long long)wave_err);
   }
 }
@@ -518,6 +521,7 @@ void Engine::solve_wave(const SolveArgs &sa, tknnSolveInfo *info, hipStream_t s)
     info->node_tests = (int64_t)h_counters_[2];
     info->point_tests = (int64_t)h_counters_[3];
     info->total_intersections = (int64_t)h_counters_[4];
+    info->total_active_rounds = (int64_t)h_counters_[6];
     info->solve_ms = ms;
     info->dominant_kernel_ms = ms;
     info->dominant_kernel_launches = 1;
