@@ -11,7 +11,8 @@ file states what that replay must come to, with none of its machinery:
     fl32(c_p - r_t) <= q <= fl32(c_p + r_t) on all three axes                 (deviceCode.cu:38-56)
   * q finishes at the first level t* at which at least k candidates other than q exist; its row
     is the k smallest (distance, index) pairs among those candidates          (deviceCode.cu:100-134,
-    ascending-index visit order)
+    ascending-index visit order); distance = sqrt((dx*dx + dy*dy) + dz*dz) in float32, each
+    operation rounded, as deviceCode.cu:110-113 is written
   * intersections(q) = sum of candidate counts (self included) over levels 0..t*   (deviceCode.cu:74)
   * rounds = 1 + max t*                                                        (hostCode.cpp:285-340)
 
@@ -23,15 +24,12 @@ import numpy as np
 from scipy.spatial import cKDTree
 
 
-def _fma32(a, b, c):
-    """fl32(a*b + c) for float32 arrays: a*b is exact in float64; see module note on double rounding."""
-    return (a.astype(np.float64) * b.astype(np.float64) + c.astype(np.float64)).astype(np.float32)
-
-
 def distance32(c_prim, org):
+    """sqrt((dx*dx + dy*dy) + dz*dz) with every operation rounded to float32 (numpy float32
+    arithmetic rounds each operation; no fused multiply-add)."""
     d = c_prim.astype(np.float32) - org.astype(np.float32)
     x, y, z = d[..., 0], d[..., 1], d[..., 2]
-    return np.sqrt(_fma32(z, z, _fma32(y, y, (x * x).astype(np.float32))))
+    return np.sqrt(((x * x) + (y * y)) + (z * z), dtype=np.float32)
 
 
 def trueknn_numpy(xyz, k, start_radius, max_rounds=64, query_ids=None):

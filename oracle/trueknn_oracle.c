@@ -35,12 +35,17 @@
  *       ascending primitive index, which together with the strict '<' of deviceCode.cu:116,125
  *       yields rows ordered by (dist, index).  Other orders are selectable to test that only
  *       ties depend on it.
- *   (3) distance arithmetic: d = sqrtf(fmaf(dz,dz, fmaf(dy,dy, dx*dx))) -- the contraction nvcc
- *       applies to deviceCode.cu:110-113 -- with a correctly rounded IEEE sqrt (the reference's
- *       Release build uses sqrt.approx.ftz, owl/cmake/configure_optix.cmake:49-53, which is not
- *       reproducible off NVIDIA hardware).
+ *   (3) distance arithmetic: d = sqrtf((dx*dx + dy*dy) + dz*dz), every operation rounded to fp32
+ *       on its own, i.e. deviceCode.cu:110-113 exactly as written, and a correctly rounded IEEE
+ *       sqrt.  The reference's Release build lets nvcc contract the sum into fmas of its choosing
+ *       and uses sqrt.approx.ftz (owl/cmake/configure_optix.cmake:49-53); neither is reproducible
+ *       off that compiler and hardware, and which products get fused differs between compilers
+ *       (hipcc's default contraction of the same line gives yet another rounding), so the
+ *       uncontracted expression is the canonical one.  The HIP engine computes it the same way,
+ *       and tools/owl_embed.py compiles user device programs with -ffp-contract=off so the
+ *       unchanged deviceCode.cu does too.
  *
- * Build: see oracle/Makefile (-ffp-contract=off so only the explicit fmaf contracts).
+ * Build: see oracle/Makefile (-ffp-contract=off: nothing contracts).
  */
 #include <float.h>
 #include <math.h>
@@ -113,7 +118,7 @@ float tkref_distance(const float *c_prim, const float *org) {
   float x = c_prim[0] - org[0];
   float y = c_prim[1] - org[1];
   float z = c_prim[2] - org[2];
-  return sqrtf(fmaf(z, z, fmaf(y, y, x * x)));
+  return sqrtf(((x * x) + (y * y)) + (z * z)); /* -ffp-contract=off: as written */
 }
 
 /* deviceCode.cu:62-138, one call per (query xID, candidate primID) */

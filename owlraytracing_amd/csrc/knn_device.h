@@ -8,15 +8,15 @@
 
 namespace owlmi {
 
-// deviceCode.cu:110-113 as nvcc contracts it: fma(dz,dz, fma(dy,dy, dx*dx)), then a correctly
-// rounded sqrt (decision (3)).  Contraction is pinned off inside these functions so that only the
-// two explicit fmas fuse whatever -ffp-contract says; __builtin_sqrtf is the IEEE-rounded sqrt
-// (HIP's __fsqrt_rn is the approximate v_sqrt_f32 unless OCML_BASIC_ROUNDED_OPERATIONS is set).
+// deviceCode.cu:110-113 exactly as written: (dx*dx + dy*dy) + dz*dz, every operation rounded to
+// fp32 (decision (3): no contraction -- which products a compiler fuses is not portable), then a
+// correctly rounded sqrt.  Contraction is pinned off inside the function whatever -ffp-contract
+// says; __builtin_sqrtf is the IEEE-rounded sqrt (HIP's __fsqrt_rn is the approximate v_sqrt_f32
+// unless OCML_BASIC_ROUNDED_OPERATIONS is set).
 __device__ __forceinline__ float knn_dist2(float cx, float cy, float cz, float ox, float oy, float oz) {
 #pragma clang fp contract(off)
   float x = cx - ox, y = cy - oy, z = cz - oz;
-  float xx = x * x;
-  return __builtin_fmaf(z, z, __builtin_fmaf(y, y, xx));
+  return ((x * x) + (y * y)) + (z * z);
 }
 __device__ __forceinline__ float knn_sqrt(float d2) { return __builtin_sqrtf(d2); }
 

@@ -1,0 +1,13 @@
+#!/bin/bash
+# Builds the test host driver and the test device programs into build/owl_tests/ (git-ignored).
+set -euo pipefail
+here=$(cd "$(dirname "$0")" && pwd)
+root=$(cd "$here/../.." && pwd)
+out=$root/build/owl_tests
+mkdir -p "$out"
+python3 "$root/tools/owl_embed.py" radiusCode "$here/radius_programs.cu" -o "$out/radiusCode.c" --keep-hsaco "$out/radius_programs.hsaco"
+g++ -O2 -std=c++17 -Wall -I"$root/include" -I"$root/include/owl_shims" -I/opt/rocm/include -D__HIP_PLATFORM_AMD__=1 \
+    "$here/owl_host_driver.cpp" -o "$out/owl_host_driver" \
+    -L"$root/owlraytracing_amd" -lowl_mi355x -L/opt/rocm/lib -lamdhip64 \
+    -Wl,-rpath,"$root/owlraytracing_amd" -Wl,-rpath,'$ORIGIN/../../owlraytracing_amd' -Wl,-rpath,/opt/rocm/lib
+echo "built $out"
