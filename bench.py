@@ -143,7 +143,7 @@ def main():
     kern_ms = float(np.mean([i["dominant_kernel_ms"] for i in infos]))
     total_isect = int(info["total_intersections"])
     total_rounds_active = int(info["total_active_rounds"])
-    n_local = n_total // world if world > 1 else n
+    n_local = len(solver.points) if world > 1 else n
     alg_bytes = algorithmic_bytes(n_local, k, total_isect, total_rounds_active)
     launches = max(int(info["dominant_kernel_launches"]), 1)
     achieved = alg_bytes / launches / (kern_ms * 1e-3) / 1e9

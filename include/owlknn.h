@@ -79,6 +79,7 @@ typedef struct {
   int32_t dominant_kernel_launches;
   int32_t kernel_used;         /* TKNN_KERNEL_*                                                   */
   int32_t list_capacity;       /* register k-list size the kernel was instantiated with           */
+  int64_t unfinished;          /* queries left without k neighbours (only with allow_unfinished)  */
 } tknnSolveInfo;
 
 typedef struct {
@@ -111,6 +112,33 @@ TKNN_API int tknnBuild(tknnEngine e, const float *d_xyz, int64_t n, tknnBuildInf
 TKNN_API int tknnSolve(tknnEngine e, int k, float start_radius, int kernel, int max_rounds,
                        int32_t *d_idx, float *d_dist, int64_t *d_intersections, tknnNeigh *d_fb,
                        tknnSolveInfo *info, void *stream);
+
+/* ---- sharded use: one engine per GPU owns a tile of a larger point set ----
+ * tknnBuildIds: like tknnBuild, but point i is reported as d_ids[i] (a global index) in neighbour
+ *   lists and excluded as "self" by that id; rows are still addressed by the local position i.
+ * tknnSetHalo: a second, read-only point set (border points received from neighbouring tiles, with
+ *   their global ids) that every query also searches; m = 0 removes it.
+ * tknnSolveEx: tknnSolve with options: d_levels (n, may be NULL) receives the 0-based radius level at
+ *   which each query finished, or -1; with allow_unfinished != 0 reaching max_rounds is not an
+ *   error: unfinished queries keep level -1, their rows are not written and info->unfinished counts
+ *   them (the caller widens the halo and solves again). */
+typedef struct {
+  int32_t k;
+  float start_radius;
+  int32_t kernel;
+  int32_t max_rounds;
+  int32_t allow_unfinished;
+  int32_t reserved_;
+  int32_t *d_idx;
+  float *d_dist;
+  int64_t *d_intersections;
+  tknnNeigh *d_fb;
+  int32_t *d_levels;
+} tknnSolveOptions;
+TKNN_API int tknnBuildIds(tknnEngine e, const float *d_xyz, const int32_t *d_ids, int64_t n,
+                          tknnBuildInfo *info, void *stream);
+TKNN_API int tknnSetHalo(tknnEngine e, const float *d_xyz, const int32_t *d_ids, int64_t m, void *stream);
+TKNN_API int tknnSolveEx(tknnEngine e, const tknnSolveOptions *options, tknnSolveInfo *info, void *stream);
 
 /* Test / debug export of the tree to host memory (any pointer may be NULL):
  *   nodes      (n-1) x 8 dwords {lo[3], split, hi[3], other}   (include/owl/lbvh_device.h)

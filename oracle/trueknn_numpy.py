@@ -32,7 +32,9 @@ def distance32(c_prim, org):
     return np.sqrt(((x * x) + (y * y)) + (z * z), dtype=np.float32)
 
 
-def trueknn_numpy(xyz, k, start_radius, max_rounds=64, query_ids=None):
+def trueknn_numpy(xyz, k, start_radius, max_rounds=64, query_ids=None, stop_quietly=False, ids=None):
+    """``ids`` (optional): identity of each point for the self test and the tie order (defaults to
+    the position); ``stop_quietly``: at max_rounds return with level -1 for unfinished queries."""
     xyz = np.ascontiguousarray(xyz, dtype=np.float32)
     if xyz.shape[1] == 2:
         xyz = np.concatenate([xyz, np.zeros((len(xyz), 1), np.float32)], 1)
@@ -48,6 +50,8 @@ def trueknn_numpy(xyz, k, start_radius, max_rounds=64, query_ids=None):
     rounds = 0
     while len(active):
         if rounds >= max_rounds:
+            if stop_quietly:
+                break
             raise RuntimeError("max_rounds reached with unfinished queries")
         r = np.float32(radius)
         reach = abs(float(r)) * 1.0001 + 1e-30 + 1e-6 * float(np.abs(xyz).max())
@@ -61,11 +65,12 @@ def trueknn_numpy(xyz, k, start_radius, max_rounds=64, query_ids=None):
             inside = np.all((lo <= xyz[q]) & (xyz[q] <= hi), axis=1)
             p = p[inside]
             isect[q] += len(p)
-            others = p[p != q]
+            others = p[p != q] if ids is None else p[ids[p] != ids[q]]
             if len(others) >= k:
                 d = distance32(xyz[others], xyz[q])
-                order = np.lexsort((others, d))[:k]
-                idx[q] = others[order]
+                names = others if ids is None else ids[others]
+                order = np.lexsort((names, d))[:k]
+                idx[q] = names[order]
                 dist[q] = d[order]
                 level_of[q] = rounds
             else:

@@ -33,10 +33,27 @@ class SolveInfo(ctypes.Structure):
         ("dominant_kernel_launches", ctypes.c_int32),
         ("kernel_used", ctypes.c_int32),
         ("list_capacity", ctypes.c_int32),
+        ("unfinished", ctypes.c_int64),
     ]
 
     def as_dict(self):
         return {name: getattr(self, name) for name, _ in self._fields_}
+
+
+class SolveOptions(ctypes.Structure):
+    _fields_ = [
+        ("k", ctypes.c_int32),
+        ("start_radius", ctypes.c_float),
+        ("kernel", ctypes.c_int32),
+        ("max_rounds", ctypes.c_int32),
+        ("allow_unfinished", ctypes.c_int32),
+        ("reserved_", ctypes.c_int32),
+        ("d_idx", ctypes.c_void_p),
+        ("d_dist", ctypes.c_void_p),
+        ("d_intersections", ctypes.c_void_p),
+        ("d_fb", ctypes.c_void_p),
+        ("d_levels", ctypes.c_void_p),
+    ]
 
 
 class BuildInfo(ctypes.Structure):
@@ -57,6 +74,12 @@ SIGNATURES = {
     "tknnSolve": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_int,
                                  ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                                  ctypes.c_void_p, ctypes.POINTER(SolveInfo), ctypes.c_void_p]),
+    "tknnBuildIds": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64,
+                                    ctypes.POINTER(BuildInfo), ctypes.c_void_p]),
+    "tknnSetHalo": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64,
+                                   ctypes.c_void_p]),
+    "tknnSolveEx": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(SolveOptions), ctypes.POINTER(SolveInfo),
+                                   ctypes.c_void_p]),
     "tknnExportTree": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                                       ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     "tknnDebugThresholds": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64,

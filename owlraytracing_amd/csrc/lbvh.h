@@ -37,7 +37,9 @@ class Lbvh {
   Lbvh &operator=(const Lbvh &) = delete;
 
   // xyz: device pointer to n packed fp32 triples (the reference's Sphere buffer, 12 B/point).
-  void build_from_points(const float *d_xyz, int64_t n, hipStream_t stream);
+  // d_ids (optional): identity of each point as the caller wants it reported (e.g. a global index
+  // when the buffer is one shard of a larger set); default is the position in d_xyz.
+  void build_from_points(const float *d_xyz, int64_t n, hipStream_t stream, const int32_t *d_ids = nullptr);
   // boxes: device pointer to n {lo[3],hi[3]} (24 B, owl::box3f) in caller primitive order.
   void build_from_boxes(const LbvhBox *d_boxes, int64_t n, hipStream_t stream);
   // same topology, new boxes (only for build_from_boxes trees)

@@ -144,7 +144,8 @@ __global__ void __launch_bounds__(kBlock) gather_kernel(const float *__restrict_
                                                        const uint32_t *__restrict__ order,
                                                        LbvhPoint *__restrict__ points,
                                                        LbvhBox *__restrict__ sorted_boxes,
-                                                       int32_t *__restrict__ prim_id) {
+                                                       int32_t *__restrict__ prim_id,
+                                                       const int32_t *__restrict__ ids) {
   int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   if (i >= n) return;
   uint32_t src = order[i];
@@ -154,7 +155,7 @@ __global__ void __launch_bounds__(kBlock) gather_kernel(const float *__restrict_
     p.x = xyz[3 * (int64_t)src];
     p.y = xyz[3 * (int64_t)src + 1];
     p.z = xyz[3 * (int64_t)src + 2];
-    p.id = (int32_t)src;
+    p.id = ids ? ids[src] : (int32_t)src;
     points[i] = p;
   } else {
     sorted_boxes[i] = boxes[src];
@@ -390,7 +391,7 @@ void Lbvh::fit(hipStream_t stream) {
   OWLMI_HIP(hipGetLastError());
 }
 
-void Lbvh::build_from_points(const float *d_xyz, int64_t n, hipStream_t stream) {
+void Lbvh::build_from_points(const float *d_xyz, int64_t n, hipStream_t stream, const int32_t *d_ids) {
   if (n <= 0 || n >= 0x7fffffffLL) throw HipError{"Lbvh: primitive count out of range"};
   reserve(n);
   n_ = n;
@@ -404,7 +405,7 @@ void Lbvh::build_from_points(const float *d_xyz, int64_t n, hipStream_t stream) 
   OWLMI_HIP(hipGetLastError());
   sort_and_tree(stream);
   hipLaunchKernelGGL(gather_kernel<true>, dim3(blocks_for(n)), dim3(kBlock), 0, stream, d_xyz,
-                     (const LbvhBox *)nullptr, n, order_alt_, points_, (LbvhBox *)nullptr, prim_id_);
+                     (const LbvhBox *)nullptr, n, order_alt_, points_, (LbvhBox *)nullptr, prim_id_, d_ids);
   OWLMI_HIP(hipGetLastError());
   fit(stream);
   built_ = true;
@@ -424,7 +425,7 @@ void Lbvh::build_from_boxes(const LbvhBox *d_boxes, int64_t n, hipStream_t strea
   OWLMI_HIP(hipGetLastError());
   sort_and_tree(stream);
   hipLaunchKernelGGL(gather_kernel<false>, dim3(blocks_for(n)), dim3(kBlock), 0, stream,
-                     (const float *)nullptr, d_boxes, n, order_alt_, (LbvhPoint *)nullptr, boxes_, prim_id_);
+                     (const float *)nullptr, d_boxes, n, order_alt_, (LbvhPoint *)nullptr, boxes_, prim_id_, (const int32_t *)nullptr);
   OWLMI_HIP(hipGetLastError());
   fit(stream);
   built_ = true;
@@ -433,7 +434,7 @@ void Lbvh::build_from_boxes(const LbvhBox *d_boxes, int64_t n, hipStream_t strea
 void Lbvh::refit_boxes(const LbvhBox *d_boxes, hipStream_t stream) {
   if (!built_ || point_mode_) throw HipError{"Lbvh::refit_boxes: no box tree to refit"};
   hipLaunchKernelGGL(gather_kernel<false>, dim3(blocks_for(n_)), dim3(kBlock), 0, stream,
-                     (const float *)nullptr, d_boxes, n_, order_alt_, (LbvhPoint *)nullptr, boxes_, prim_id_);
+                     (const float *)nullptr, d_boxes, n_, order_alt_, (LbvhPoint *)nullptr, boxes_, prim_id_, (const int32_t *)nullptr);
   OWLMI_HIP(hipGetLastError());
   fit(stream);
 }

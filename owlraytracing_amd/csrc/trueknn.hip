@@ -22,6 +22,9 @@ constexpr int kLaneBlock = 256;
 
 struct LaneRoundArgs {
   LbvhView bvh;
+  LbvhView halo;           // second point set searched by every query (n == 0: none)
+  int level;               // 0-based radius level of this launch
+  int32_t *out_level;      // n, caller order (may be null)
   float radius;
   int k;
   uint8_t *done;           // per sorted slot
@@ -34,10 +37,10 @@ struct LaneRoundArgs {
 };
 
 template <int K>
-__device__ __forceinline__ void write_row(const LaneRoundArgs &a, int32_t qid, const KList<K> &list,
+__device__ __forceinline__ void write_row(const LaneRoundArgs &a, int32_t row, const KList<K> &list,
                                           int64_t isect) {
   const int k = a.k;
-  const int64_t base = (int64_t)qid * k;
+  const int64_t base = (int64_t)row * k;
 #pragma unroll
   for (int j = 0; j < K; j++) {
     if (j < k) {
@@ -58,7 +61,8 @@ __device__ __forceinline__ void write_row(const LaneRoundArgs &a, int32_t qid, c
       }
     }
   }
-  if (a.out_isect) a.out_isect[qid] = isect;
+  if (a.out_isect) a.out_isect[row] = isect;
+  if (a.out_level) a.out_level[row] = a.level;
 }
 
 template <int K>
@@ -75,29 +79,33 @@ __global__ void __launch_bounds__(kLaneBlock) lane_round_kernel(LaneRoundArgs a)
   list.clear();
   int32_t cnt = 0, others = 0;
   uint32_t node_tests = 0, point_tests = 0;
-  int32_t ref = active ? bvh.root : LBVH_END;
-  while (ref != LBVH_END) {
-    if (ref >= 0) {
-      const LbvhNode nd = bvh.nodes[ref];
-      node_tests++;
-      // conservative: any point p in the node has lo <= c_p <= hi, and fp32 rounding is monotone,
-      // so fl(c_p - r) >= fl(lo - r) and fl(c_p + r) <= fl(hi + r)
-      bool hit = (nd.lo[0] - r <= q.x) & (q.x <= nd.hi[0] + r) & (nd.lo[1] - r <= q.y) &
-                 (q.y <= nd.hi[1] + r) & (nd.lo[2] - r <= q.z) & (q.z <= nd.hi[2] + r);
-      ref = hit ? lbvh_left_ref(ref, nd) : bvh.rope_node[ref];
-    } else {
-      const int32_t slot = ~ref;
-      const LbvhPoint p = bvh.points[slot];
-      point_tests++;
-      if (knn_in_box(p.x, p.y, p.z, r, q.x, q.y, q.z)) {
-        cnt++;                 // deviceCode.cu:74
-        if (p.id != q.id) {    // deviceCode.cu:103
-          others++;
-          float d = knn_sqrt(knn_dist2(p.x, p.y, p.z, q.x, q.y, q.z));
-          list.insert(knn_key(d, p.id));
+  for (int tree = 0; tree < 2; tree++) {
+    const LbvhView &tv = tree == 0 ? a.bvh : a.halo;
+    if (tv.n <= 0) continue;
+    int32_t ref = active ? tv.root : LBVH_END;
+    while (ref != LBVH_END) {
+      if (ref >= 0) {
+        const LbvhNode nd = tv.nodes[ref];
+        node_tests++;
+        // conservative: any point p in the node has lo <= c_p <= hi, and fp32 rounding is monotone,
+        // so fl(c_p - r) >= fl(lo - r) and fl(c_p + r) <= fl(hi + r)
+        bool hit = (nd.lo[0] - r <= q.x) & (q.x <= nd.hi[0] + r) & (nd.lo[1] - r <= q.y) &
+                   (q.y <= nd.hi[1] + r) & (nd.lo[2] - r <= q.z) & (q.z <= nd.hi[2] + r);
+        ref = hit ? lbvh_left_ref(ref, nd) : tv.rope_node[ref];
+      } else {
+        const int32_t slot = ~ref;
+        const LbvhPoint p = tv.points[slot];
+        point_tests++;
+        if (knn_in_box(p.x, p.y, p.z, r, q.x, q.y, q.z)) {
+          cnt++;                 // deviceCode.cu:74
+          if (p.id != q.id) {    // deviceCode.cu:103
+            others++;
+            float d = knn_sqrt(knn_dist2(p.x, p.y, p.z, q.x, q.y, q.z));
+            list.insert(knn_key(d, p.id));
+          }
         }
+        ref = tv.rope_leaf[slot];
       }
-      ref = bvh.rope_leaf[slot];
     }
   }
   int64_t isect = 0;
@@ -108,7 +116,7 @@ __global__ void __launch_bounds__(kLaneBlock) lane_round_kernel(LaneRoundArgs a)
     finished = others >= a.k;  // k insertions happened <=> numNeighbors reached 0
     if (finished) {
       a.done[t] = 1;
-      write_row<K>(a, q.id, list, isect);
+      write_row<K>(a, bvh.prim_id[t], list, isect);
     }
   }
   // wave-aggregated counters (all 64 lanes are here)
@@ -167,9 +175,25 @@ Engine::~Engine() {
   if (ev_b_) (void)hipEventDestroy(ev_b_);
 }
 
-void Engine::build(const float *d_xyz, int64_t n, tknnBuildInfo *info, hipStream_t s) {
+void Engine::set_halo(const float *d_xyz, const int32_t *d_ids, int64_t m, hipStream_t s) {
+  halo_n_ = 0;
+  if (m <= 0) return;
+  halo_.build_from_points(d_xyz, m, s, d_ids);
+  halo_n_ = m;
+}
+
+LbvhView Engine::halo_view() const {
+  if (halo_n_ > 0) return halo_.view();
+  LbvhView v;
+  std::memset(&v, 0, sizeof v);
+  v.root = LBVH_END;
+  return v;
+}
+
+void Engine::build(const float *d_xyz, const int32_t *d_ids, int64_t n, tknnBuildInfo *info, hipStream_t s) {
   OWLMI_HIP(hipEventRecord(ev_a_, s));
-  bvh_.build_from_points(d_xyz, n, s);
+  halo_n_ = 0;
+  bvh_.build_from_points(d_xyz, n, s, d_ids);
   OWLMI_HIP(hipEventRecord(ev_b_, s));
   if (n > state_cap_) {
     if (done_) (void)hipFree(done_);
@@ -196,8 +220,11 @@ void Engine::solve_lane(const SolveArgs &sa, tknnSolveInfo *info, hipStream_t s)
   OWLMI_HIP(hipMemsetAsync(done_, 0, (size_t)n, s));
   OWLMI_HIP(hipMemsetAsync(isect_sorted_, 0, (size_t)n * sizeof(int64_t), s));
   OWLMI_HIP(hipMemsetAsync(counters_, 0, 16 * sizeof(unsigned long long), s));
+  if (sa.d_levels) OWLMI_HIP(hipMemsetAsync(sa.d_levels, 0xff, (size_t)n * sizeof(int32_t), s));
   LaneRoundArgs a;
   a.bvh = bvh_.view();
+  a.halo = halo_view();
+  a.out_level = sa.d_levels;
   a.k = sa.k;
   a.done = done_;
   a.isect_sorted = isect_sorted_;
@@ -209,7 +236,11 @@ void Engine::solve_lane(const SolveArgs &sa, tknnSolveInfo *info, hipStream_t s)
   float radius = sa.start_radius, total_ms = 0;
   int rounds = 0;
   for (;;) {
-    if (rounds >= sa.max_rounds) throw RoundsExceeded{};
+    if (rounds >= sa.max_rounds) {
+      if (sa.allow_unfinished) break;
+      throw RoundsExceeded{};
+    }
+    a.level = rounds;
     rounds++;
     a.radius = radius;
     OWLMI_HIP(hipMemsetAsync(counters_, 0, sizeof(unsigned long long), s));  // [0] only
@@ -235,6 +266,7 @@ void Engine::solve_lane(const SolveArgs &sa, tknnSolveInfo *info, hipStream_t s)
     OWLMI_HIP(hipEventElapsedTime(&ms, ev_a_, ev_b_));
     total_ms += ms;
     if (h_counters_[0] == 0) break;
+    if (rounds >= sa.max_rounds && sa.allow_unfinished) break;
     radius *= 2;  // hostCode.cpp:321 (fp32)
   }
   if (info) {
@@ -249,6 +281,7 @@ void Engine::solve_lane(const SolveArgs &sa, tknnSolveInfo *info, hipStream_t s)
     info->dominant_kernel_launches = rounds;
     info->kernel_used = TKNN_KERNEL_LANE;
     info->list_capacity = cap;
+    info->unfinished = (int64_t)h_counters_[0];
   }
 }
 
@@ -319,25 +352,61 @@ int tknnCreate(tknnEngine *out) {
 
 void tknnDestroy(tknnEngine e) { delete e; }
 
-int tknnBuild(tknnEngine e, const float *d_xyz, int64_t n, tknnBuildInfo *info, void *stream) {
+int tknnBuildIds(tknnEngine e, const float *d_xyz, const int32_t *d_ids, int64_t n, tknnBuildInfo *info,
+                 void *stream) {
   if (!e || !d_xyz || n <= 0 || n >= 0x7fffffffLL) {
     g_last_error = "tknnBuild: need an engine, a device pointer and 0 < n < 2^31-1";
     return TKNN_E_ARG;
   }
-  return guarded([&] { e->impl.build(d_xyz, n, info, (hipStream_t)stream); });
+  return guarded([&] { e->impl.build(d_xyz, d_ids, n, info, (hipStream_t)stream); });
+}
+
+int tknnBuild(tknnEngine e, const float *d_xyz, int64_t n, tknnBuildInfo *info, void *stream) {
+  return tknnBuildIds(e, d_xyz, nullptr, n, info, stream);
+}
+
+int tknnSetHalo(tknnEngine e, const float *d_xyz, const int32_t *d_ids, int64_t m, void *stream) {
+  if (!e || m < 0 || m >= 0x7fffffffLL || (m > 0 && (!d_xyz || !d_ids))) {
+    g_last_error = "tknnSetHalo: need an engine and, for m > 0, device pointers to points and ids";
+    return TKNN_E_ARG;
+  }
+  return guarded([&] {
+    if (!e->impl.built()) throw owlmi::ArgError{TKNN_E_STATE, "tknnSetHalo: call tknnBuild first"};
+    e->impl.set_halo(d_xyz, d_ids, m, (hipStream_t)stream);
+  });
 }
 
 int tknnSolve(tknnEngine e, int k, float start_radius, int kernel, int max_rounds, int32_t *d_idx,
               float *d_dist, int64_t *d_intersections, tknnNeigh *d_fb, tknnSolveInfo *info, void *stream) {
-  if (!e) {
-    g_last_error = "tknnSolve: engine is NULL";
+  tknnSolveOptions o;
+  std::memset(&o, 0, sizeof o);
+  o.k = k;
+  o.start_radius = start_radius;
+  o.kernel = kernel;
+  o.max_rounds = max_rounds;
+  o.d_idx = d_idx;
+  o.d_dist = d_dist;
+  o.d_intersections = d_intersections;
+  o.d_fb = d_fb;
+  return tknnSolveEx(e, &o, info, stream);
+}
+
+int tknnSolveEx(tknnEngine e, const tknnSolveOptions *options, tknnSolveInfo *info, void *stream) {
+  if (!e || !options) {
+    g_last_error = "tknnSolve: engine or options is NULL";
     return TKNN_E_ARG;
   }
+  const int k = options->k, kernel = options->kernel, max_rounds = options->max_rounds;
+  const float start_radius = options->start_radius;
+  int32_t *d_idx = options->d_idx;
+  float *d_dist = options->d_dist;
+  int64_t *d_intersections = options->d_intersections;
+  tknnNeigh *d_fb = options->d_fb;
   return guarded([&] {
     if (!e->impl.built()) throw owlmi::ArgError{TKNN_E_STATE, "tknnSolve: call tknnBuild first"};
     if (k <= 0) throw owlmi::ArgError{TKNN_E_ARG, "tknnSolve: k must be positive"};
     if (k > TKNN_MAX_K) throw owlmi::ArgError{TKNN_E_UNSUPPORTED, "tknnSolve: k exceeds TKNN_MAX_K"};
-    if ((int64_t)k >= e->impl.size())
+    if ((int64_t)k >= e->impl.size() && !options->allow_unfinished)
       throw owlmi::ArgError{TKNN_E_ARG, "tknnSolve: need n > k (the reference never terminates otherwise)"};
     if (!(start_radius > 0.f) || !std::isfinite(start_radius))
       throw owlmi::ArgError{TKNN_E_ARG, "tknnSolve: start_radius must be finite and > 0"};
@@ -351,6 +420,8 @@ int tknnSolve(tknnEngine e, int k, float start_radius, int kernel, int max_round
     sa.d_dist = d_dist;
     sa.d_isect = d_intersections;
     sa.d_fb = d_fb;
+    sa.d_levels = options->d_levels;
+    sa.allow_unfinished = options->allow_unfinished != 0;
     if (info) std::memset(info, 0, sizeof(*info));
     e->impl.solve(sa, kernel, info, (hipStream_t)stream);
   });

@@ -25,6 +25,8 @@ struct SolveArgs {
   float *d_dist = nullptr;
   int64_t *d_isect = nullptr;
   tknnNeigh *d_fb = nullptr;
+  int32_t *d_levels = nullptr;
+  bool allow_unfinished = false;
 };
 
 // smallest register-list capacity instantiated for k, or -1
@@ -40,7 +42,9 @@ class Engine {
   Engine(const Engine &) = delete;
   Engine &operator=(const Engine &) = delete;
 
-  void build(const float *d_xyz, int64_t n, tknnBuildInfo *info, hipStream_t s);
+  void build(const float *d_xyz, const int32_t *d_ids, int64_t n, tknnBuildInfo *info, hipStream_t s);
+  void set_halo(const float *d_xyz, const int32_t *d_ids, int64_t m, hipStream_t s);
+  LbvhView halo_view() const;
   void solve(const SolveArgs &sa, int kernel, tknnSolveInfo *info, hipStream_t s);
   bool built() const { return bvh_.built(); }
   int64_t size() const { return bvh_.size(); }
@@ -53,6 +57,8 @@ class Engine {
 
   int device_ = 0;
   Lbvh bvh_;
+  Lbvh halo_;
+  int64_t halo_n_ = 0;
   uint8_t *done_ = nullptr;
   int64_t *isect_sorted_ = nullptr;
   int64_t state_cap_ = 0;

@@ -40,6 +40,9 @@ constexpr int kWaveLds = kStackCap * 4 + kQueueDepth * 64 * 8;  // 8 KiB per wav
 
 struct WaveArgs {
   LbvhView bvh;
+  LbvhView halo;      // second point set searched by every query (n == 0: none)
+  int32_t *out_level; // n, caller order (may be null)
+  int allow_unfinished;
   float start_radius;
   int k;
   int max_rounds;
@@ -194,9 +197,10 @@ __device__ __forceinline__ void flush_queue(LaneState<K> &st, const uint64_t *qu
 }
 
 template <int K>
-__device__ __forceinline__ void emit_row(const WaveArgs &a, int32_t qid, const KList<K> &list, int64_t isect) {
+__device__ __forceinline__ void emit_row(const WaveArgs &a, int32_t row, int level, const KList<K> &list,
+                                         int64_t isect) {
   const int k = a.k;
-  const int64_t base = (int64_t)qid * k;
+  const int64_t base = (int64_t)row * k;
 #pragma unroll
   for (int j = 0; j < K; j++) {
     if (j < k) {
@@ -215,7 +219,8 @@ __device__ __forceinline__ void emit_row(const WaveArgs &a, int32_t qid, const K
       }
     }
   }
-  if (a.out_isect) a.out_isect[qid] = isect;
+  if (a.out_isect) a.out_isect[row] = isect;
+  if (a.out_level) a.out_level[row] = level;
 }
 
 template <int K>
@@ -227,7 +232,7 @@ __global__ void __launch_bounds__(kWaveBlock) wave_packet_kernel(WaveArgs a) {
   uint64_t *queue = (uint64_t *)(smem + wid * kWaveLds + kStackCap * 4);
   const LbvhView &bvh = a.bvh;
 
-  unsigned long long my_isect_sum = 0, my_levels = 0, wave_node_tests = 0, wave_point_tests = 0;
+  unsigned long long my_isect_sum = 0, my_levels = 0, my_unfinished = 0, wave_node_tests = 0, wave_point_tests = 0;
   int wave_levels = 0, wave_err = 0;
 
   for (;;) {
@@ -291,8 +296,11 @@ __global__ void __launch_bounds__(kWaveBlock) wave_packet_kernel(WaveArgs a) {
         pend_count = 0;
       };
 
+      for (int tree = 0; tree < 2 && !wave_err; tree++) {
+      const LbvhView &tv = tree == 0 ? a.bvh : a.halo;
+      if (tv.n <= 0) continue;
       int sp = 1;
-      if (lane == 0) stack[0] = bvh.root;
+      if (lane == 0) stack[0] = tv.root;
       wave_lds_sync();
 
       while (sp > 0) {
@@ -315,9 +323,9 @@ __global__ void __launch_bounds__(kWaveBlock) wave_packet_kernel(WaveArgs a) {
         LbvhPoint np = {0.f, 0.f, 0.f, -1};
         if (lane < w) {
           if (ref >= 0)
-            nd = bvh.nodes[ref];
+            nd = tv.nodes[ref];
           else
-            np = bvh.points[~ref];
+            np = tv.points[~ref];
         }
         if (pend_count) process_pending();
 
@@ -376,12 +384,13 @@ __global__ void __launch_bounds__(kWaveBlock) wave_packet_kernel(WaveArgs a) {
           const int r_count = __builtin_amdgcn_readlane(count, src);
           wave_point_tests += (unsigned long long)r_count * (unsigned)__popcll(takers);
           LbvhPoint nxt = {0.f, 0.f, 0.f, -1};
-          if (lane < r_count) nxt = bvh.points[r_first + lane];
+          if (lane < r_count) nxt = tv.points[r_first + lane];
           if (pend_count) process_pending();
           pend = nxt;
           pend_count = r_count;
         }
       }
+      }  // trees
       if (pend_count) process_pending();
       flush_queue<K>(st, queue, lane);
 
@@ -391,7 +400,7 @@ __global__ void __launch_bounds__(kWaveBlock) wave_packet_kernel(WaveArgs a) {
         isect += st.cnt;
         finished = st.others >= (uint32_t)a.k;
         if (finished) {
-          emit_row<K>(a, q.id, st.list, isect);
+          emit_row<K>(a, bvh.prim_id[slot], level, st.list, isect);
           my_isect_sum += (unsigned long long)isect;
         }
       }
@@ -399,23 +408,26 @@ __global__ void __launch_bounds__(kWaveBlock) wave_packet_kernel(WaveArgs a) {
       level++;
       if (__ballot(active) == 0ull || wave_err) break;
       if (level >= a.max_rounds) {
-        wave_err |= 1;
+        if (!a.allow_unfinished) wave_err |= 1;
         break;
       }
       r = r * 2.0f;  // hostCode.cpp:321
     }
     wave_levels = max(wave_levels, level);
+    if (active) my_unfinished++;
   }
 
   // once per wave lifetime
   const unsigned long long isum = wave_sum(my_isect_sum);
   const unsigned long long lsum = wave_sum(my_levels);
+  const unsigned long long usum = wave_sum(my_unfinished);
   if (lane == 0) {
     atomicMax(&a.counters[1], (unsigned long long)wave_levels);
     atomicAdd(&a.counters[2], wave_node_tests);
     atomicAdd(&a.counters[3], wave_point_tests);
     atomicAdd(&a.counters[4], isum);
     atomicAdd(&a.counters[6], lsum);
+    if (usum) atomicAdd(&a.counters[7], usum);
     if (wave_err) atomicOr(&a.counters[5], (unsigned long long)wave_err);
   }
 }
@@ -457,6 +469,9 @@ void Engine::solve_wave(const SolveArgs &sa, tknnSolveInfo *info, hipStream_t s)
   const int cap = list_capacity_for(sa.k);
   WaveArgs a;
   a.bvh = bvh_.view();
+  a.halo = halo_view();
+  a.out_level = sa.d_levels;
+  a.allow_unfinished = sa.allow_unfinished ? 1 : 0;
   a.start_radius = sa.start_radius;
   a.k = sa.k;
   a.max_rounds = sa.max_rounds;
@@ -487,6 +502,7 @@ void Engine::solve_wave(const SolveArgs &sa, tknnSolveInfo *info, hipStream_t s)
   const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>(want, (int64_t)prop.multiProcessorCount * per_cu));
 
   OWLMI_HIP(hipMemsetAsync(counters_, 0, 16 * sizeof(unsigned long long), s));
+  if (sa.d_levels) OWLMI_HIP(hipMemsetAsync(sa.d_levels, 0xff, (size_t)n * sizeof(int32_t), s));
   OWLMI_HIP(hipEventRecord(ev_a_, s));
   switch (cap) {
     case 1: launch_wave<1>(a, blocks, s); break;
@@ -527,6 +543,7 @@ void Engine::solve_wave(const SolveArgs &sa, tknnSolveInfo *info, hipStream_t s)
     info->dominant_kernel_launches = 1;
     info->kernel_used = TKNN_KERNEL_WAVE;
     info->list_capacity = cap;
+    info->unfinished = (int64_t)h_counters_[7];
   }
 }
 

@@ -1,0 +1,226 @@
+"""Multi-GPU TrueKNN: Morton tiles + halo exchange.
+
+The reference has no multi-GPU path for this workload (it replicates every buffer and the BVH on
+every device and pins the sample to one GPU, owl/RayGen.cpp:150-200, hostCode.cpp:141).  Here the
+path shards naturally -- queries are independent -- with ONE real exchange step:
+
+  * the global point set is cut into W contiguous ranges of the 63-bit Morton order with equal
+    counts (splitters from a sorted sample); rank g owns the queries and result rows of tile g and
+    keeps an LBVH over its own points (built once, like the single-GPU build);
+  * per solve, every rank sends each peer the points of its tile that lie within the halo radius of
+    the peer's tile bounding box -- exactly the foreign points that can be box candidates of the
+    peer's queries (the reference's candidate test is an L-inf box) -- as one
+    point-to-point exchange (RCCL send/recv over xGMI; a few MB per pair, latency-bound);
+  * the engine searches own tree + halo tree; a query's row is exact as soon as its final radius
+    does not exceed the halo radius, which one 8-byte all-reduce checks; stragglers double the halo
+    radius and go again.  Neighbour indices are global, so rows equal the single-GPU result.
+
+One process per GPU (torch.distributed, backend "nccl" = RCCL on ROCm); with backend "gloo" the
+same code runs with host-staged messages (CPU tests, or several ranks sharing one GPU).
+"""
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from . import _lib, datasets
+
+
+def morton63(points, lo, extent):
+    """63-bit Morton codes (21 bits per axis, x most significant) of float32 points, as int64."""
+    scale = 2097151.0 / extent if extent > 0 else 0.0
+    q = ((points.double() - lo.double()) * scale).clamp_(0, 2097151).long()
+
+    def spread(v):
+        v = v & 0x1FFFFF
+        v = (v | (v << 32)) & 0x1F00000000FFFF
+        v = (v | (v << 16)) & 0x1F0000FF0000FF
+        v = (v | (v << 8)) & 0x100F00F00F00F00F
+        v = (v | (v << 4)) & 0x10C30C30C30C30C3
+        v = (v | (v << 2)) & 0x1249249249249249
+        return v
+
+    return (spread(q[:, 0]) << 2) | (spread(q[:, 1]) << 1) | spread(q[:, 2])
+
+
+class _Comm:
+    """The three collectives the path needs, on device tensors (nccl) or host-staged (gloo)."""
+
+    def __init__(self, group=None):
+        self.group = group
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+        self.staged = dist.get_backend(group) != "nccl"
+
+    def _wire(self, t):
+        return t.cpu() if self.staged and t.is_cuda else t
+
+    def all_reduce(self, t, op):
+        w = self._wire(t)
+        dist.all_reduce(w, op=op, group=self.group)
+        if w is not t:
+            t.copy_(w)
+        return t
+
+    def all_gather(self, t):
+        w = self._wire(t.contiguous())
+        out = [torch.empty_like(w) for _ in range(self.world)]
+        dist.all_gather(out, w, group=self.group)
+        return torch.stack(out).to(t.device)
+
+    def exchange_rows(self, rows_per_peer, width, dtype, device):
+        """all-to-all-v of 2-D row blocks: rows_per_peer[p] goes to rank p; returns the list of
+        blocks received (index = source rank).  Counts first, then one batched send/recv."""
+        counts = torch.tensor([len(r) for r in rows_per_peer], dtype=torch.int64, device=device)
+        counts_in = self.all_gather(counts)[:, self.rank].tolist()  # [src] rows coming from src
+        recv = [torch.empty((int(c), width), dtype=dtype, device="cpu" if self.staged else device) for c in counts_in]
+        ops = []
+        for p in range(self.world):
+            if p == self.rank:
+                continue
+            if len(rows_per_peer[p]):
+                ops.append(dist.P2POp(dist.isend, self._wire(rows_per_peer[p].contiguous()), p, group=self.group))
+            if counts_in[p]:
+                ops.append(dist.P2POp(dist.irecv, recv[p], p, group=self.group))
+        if ops:
+            for req in dist.batch_isend_irecv(ops):
+                req.wait()
+        recv[self.rank] = rows_per_peer[self.rank]
+        return [r.to(device) for r in recv]
+
+
+class ShardedTrueKNN:
+    """TrueKNN over a point set sharded across the ranks of a process group.
+
+    ``engine_factory(device)`` must return an object with the ``owlraytracing_amd.trueknn.TrueKNN``
+    interface (build / set_halo / solve); the default is that class, i.e. the HIP engine.  Tests
+    inject a checker-backed stand-in to run the partition / halo / validity logic on CPU ranks.
+    """
+
+    def __init__(self, device, kernel=_lib.KERNEL_AUTO, engine_factory=None, group=None, halo_levels=2):
+        self.device = torch.device(device)
+        self.kernel = kernel
+        self.comm = _Comm(group)
+        if engine_factory is None:
+            from .trueknn import TrueKNN
+            engine_factory = lambda dev: TrueKNN(device=dev.index)  # noqa: E731
+        self.engine = engine_factory(self.device)
+        self.halo_levels = halo_levels  # first halo radius = start_radius * 2**halo_levels
+        self.points = None      # (m,3) float32 owned points, on self.device
+        self.ids = None         # (m,) int32 global ids of the owned points
+        self.tile_boxes = None  # (W,6) float64: lo xyz, hi xyz of every rank's tile
+        self.n_total = 0
+        self.last = None
+
+    # ---- one-time distribution -------------------------------------------------------------
+    def load_counter_based(self, n_total, seed=0):
+        """Every rank generates its slice of the C4-style counter-based uniform set, then tiles."""
+        w, r = self.comm.world, self.comm.rank
+        lo, hi = n_total * r // w, n_total * (r + 1) // w
+        pts = torch.from_numpy(datasets.uniform3d_counter(lo, hi, seed=seed)).to(self.device)
+        ids = torch.arange(lo, hi, dtype=torch.int32, device=self.device)
+        self.load_points(pts, ids)
+
+    def load_points(self, points, ids):
+        """Redistribute (points, global ids) so that rank g holds Morton tile g; build own tree."""
+        comm, dev = self.comm, self.device
+        if isinstance(points, np.ndarray):
+            points = torch.from_numpy(datasets.pad_to_3d(points))
+        if isinstance(ids, np.ndarray):
+            ids = torch.from_numpy(np.ascontiguousarray(ids, dtype=np.int32))
+        points, ids = points.to(dev).float().contiguous(), ids.to(dev).int().contiguous()
+        big = torch.finfo(torch.float32).max
+        lo = points.min(0).values.double() if len(points) else torch.full((3,), big, dtype=torch.float64, device=dev)
+        hi = points.max(0).values.double() if len(points) else torch.full((3,), -big, dtype=torch.float64, device=dev)
+        comm.all_reduce(lo, dist.ReduceOp.MIN)
+        comm.all_reduce(hi, dist.ReduceOp.MAX)
+        extent = float((hi - lo).max())
+        codes = morton63(points, lo, extent)
+        order = torch.argsort(codes)
+        codes, points, ids = codes[order], points[order], ids[order]
+        # splitters: W-quantiles of the union of per-rank sorted samples
+        s = 1024
+        pick = torch.linspace(0, max(len(codes) - 1, 0), s, device=dev).long()
+        sample = codes[pick] if len(codes) else torch.full((s,), 2 ** 62, dtype=torch.int64, device=dev)
+        allsamp = comm.all_gather(sample).flatten().sort().values
+        cut = torch.tensor([len(allsamp) * (g + 1) // comm.world for g in range(comm.world - 1)], device=dev).long()
+        splitters = allsamp[cut] if comm.world > 1 else allsamp[:0]
+        dest = torch.searchsorted(splitters, codes, right=True)
+        rows = torch.cat([points, ids.view(torch.float32).unsqueeze(1)], dim=1)  # 16-byte rows: x y z id-bits
+        blocks = [rows[dest == p] for p in range(comm.world)]
+        got = torch.cat(comm.exchange_rows(blocks, 4, torch.float32, dev), dim=0)
+        self.points = got[:, :3].contiguous()
+        self.ids = got[:, 3].contiguous().view(torch.int32)
+        n_local = torch.tensor([len(self.points)], dtype=torch.int64, device=dev)
+        self.n_total = int(comm.all_reduce(n_local.clone(), dist.ReduceOp.SUM).item())
+        if len(self.points) == 0:
+            raise RuntimeError("rank %d received an empty tile; use fewer ranks for this point set" % comm.rank)
+        box = torch.cat([self.points.min(0).values, self.points.max(0).values]).double()
+        self.tile_boxes = comm.all_gather(box)
+        self.engine.build(self.points, self.ids)
+
+    # ---- per-solve exchange ---------------------------------------------------------------------
+    def _halo_blocks(self, radius):
+        """rows of my tile within `radius` (L-inf, with rounding slack) of each peer's tile box"""
+        reach = float(radius) * (1.0 + 1e-5) + 1e-30
+        p64 = self.points.double()
+        rows = torch.cat([self.points, self.ids.view(torch.float32).unsqueeze(1)], dim=1)
+        blocks = []
+        for p in range(self.comm.world):
+            if p == self.comm.rank:
+                blocks.append(rows[:0])
+                continue
+            lo, hi = self.tile_boxes[p, :3] - reach, self.tile_boxes[p, 3:] + reach
+            slack = 1e-6 * p64.abs()  # fl(c +- r) may move a box face by an ulp of the coordinate
+            mask = ((p64 + slack >= lo) & (p64 - slack <= hi)).all(dim=1)
+            blocks.append(rows[mask])
+        return blocks
+
+    def solve(self, k, start_radius, max_rounds=64, want_fb=False):
+        comm, dev = self.comm, self.device
+        r0 = np.float32(start_radius)
+        level_cap = self.halo_levels
+        exchanges, halo_points = 0, 0
+        while True:
+            halo_radius = np.float32(r0)
+            for _ in range(level_cap):
+                halo_radius = np.float32(halo_radius * np.float32(2))
+            got = comm.exchange_rows(self._halo_blocks(halo_radius), 4, torch.float32, dev)
+            got[comm.rank] = got[comm.rank][:0]
+            halo = torch.cat(got, dim=0)
+            exchanges += 1
+            halo_points = len(halo)
+            self.engine.set_halo(halo[:, :3].contiguous(), halo[:, 3].contiguous().view(torch.int32))
+            # levels 0..level_cap are exact with this halo; stop there and see who is left
+            res = self.engine.solve(k, float(r0), kernel=self.kernel, max_rounds=level_cap + 1,
+                                    want_fb=want_fb, want_levels=True, allow_unfinished=True)
+            left = torch.tensor([int(res["info"]["unfinished"])], dtype=torch.int64, device=dev)
+            comm.all_reduce(left, dist.ReduceOp.SUM)
+            if int(left.item()) == 0:
+                break
+            if level_cap + 1 >= max_rounds:
+                raise _lib.TknnError(-4, "max_rounds reached with unfinished queries")
+            level_cap += 1  # stragglers need the next radius level: widen the halo and solve again
+        rounds = torch.tensor([int(res["info"]["rounds"])], dtype=torch.int64, device=dev)
+        comm.all_reduce(rounds, dist.ReduceOp.MAX)
+        info = dict(res["info"])
+        info["rounds"] = int(rounds.item())
+        info["halo_exchanges"] = exchanges
+        info["halo_points"] = halo_points
+        info["halo_levels"] = level_cap
+        self.last = res
+        self.last["info"] = info
+        return info
+
+    def gather_rows(self):
+        """(global_ids, idx, dist, intersections) of every rank concatenated on every rank (tests)."""
+        comm, dev = self.comm, self.device
+        k = self.last["idx"].shape[1]
+        rows = torch.cat([self.ids.view(-1, 1).to(torch.float64), self.last["idx"].to(torch.float64),
+                          self.last["dist"].to(torch.float64),
+                          self.last["intersections"].view(-1, 1).to(torch.float64)], dim=1)
+        blocks = [rows for _ in range(comm.world)]
+        got = torch.cat(comm.exchange_rows(blocks, rows.shape[1], torch.float64, dev), dim=0).cpu().numpy()
+        order = np.argsort(got[:, 0])
+        got = got[order]
+        return (got[:, 0].astype(np.int64), got[:, 1:1 + k].astype(np.int32),
+                got[:, 1 + k:1 + 2 * k].astype(np.float32), got[:, 1 + 2 * k].astype(np.int64))

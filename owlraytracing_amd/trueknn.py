@@ -48,23 +48,56 @@ class TrueKNN:
     def _stream(self):
         return ctypes.c_void_p(self._torch.cuda.current_stream(self.device).cuda_stream)
 
-    def build(self, points):
+    def _points(self, points):
         torch = self._torch
         if isinstance(points, np.ndarray):
             points = torch.from_numpy(pad_to_3d(points)).to(self.device)
         if points.dtype != torch.float32 or points.dim() != 2 or points.shape[1] != 3 or not points.is_cuda:
             raise ValueError("points must be float32 (n,3) on the GPU")
-        points = points.contiguous()
+        return points.contiguous()
+
+    def _ids(self, ids, n):
+        torch = self._torch
+        if ids is None:
+            return None
+        if isinstance(ids, np.ndarray):
+            ids = torch.from_numpy(np.ascontiguousarray(ids, dtype=np.int32)).to(self.device)
+        if ids.dtype != torch.int32 or ids.dim() != 1 or ids.shape[0] != n or not ids.is_cuda:
+            raise ValueError("ids must be int32 (n,) on the GPU")
+        return ids.contiguous()
+
+    def build(self, points, ids=None):
+        """LBVH over the points.  ``ids`` (optional int32) are the identities reported in neighbour
+        lists (global indices when these points are one tile of a larger set)."""
+        torch = self._torch
+        points = self._points(points)
+        ids = self._ids(ids, points.shape[0])
         info = _lib.BuildInfo()
         with torch.cuda.device(self.device):
-            _lib.check(self._lib.tknnBuild(self._h, ctypes.c_void_p(points.data_ptr()), points.shape[0],
-                                           ctypes.byref(info), self._stream()))
+            _lib.check(self._lib.tknnBuildIds(self._h, ctypes.c_void_p(points.data_ptr()),
+                                              None if ids is None else ctypes.c_void_p(ids.data_ptr()),
+                                              points.shape[0], ctypes.byref(info), self._stream()))
         self.n = int(points.shape[0])
         self.build_info = info.as_dict()
         return self.build_info
 
+    def set_halo(self, points=None, ids=None):
+        """Second point set every query also searches (border points of neighbouring tiles)."""
+        torch = self._torch
+        with torch.cuda.device(self.device):
+            if points is None or len(points) == 0:
+                _lib.check(self._lib.tknnSetHalo(self._h, None, None, 0, self._stream()))
+                return
+            points = self._points(points)
+            ids = self._ids(ids, points.shape[0])
+            if ids is None:
+                raise ValueError("halo points need ids")
+            _lib.check(self._lib.tknnSetHalo(self._h, ctypes.c_void_p(points.data_ptr()),
+                                             ctypes.c_void_p(ids.data_ptr()), points.shape[0], self._stream()))
+            torch.cuda.current_stream(self.device).synchronize()  # the engine copied what it needs
+
     def solve(self, k, start_radius, kernel=_lib.KERNEL_AUTO, max_rounds=64, want_fb=False,
-              out=None):
+              out=None, want_levels=False, allow_unfinished=False):
         """Returns dict(idx (n,k) int32, dist (n,k) f32, intersections (n,) int64[, fb (n*k*24,) uint8])
         as CUDA tensors plus ``info``.  ``out`` may carry preallocated tensors of those names."""
         torch = self._torch
@@ -77,15 +110,22 @@ class TrueKNN:
                 out.setdefault("intersections", torch.empty((n,), dtype=torch.int64, device=self.device))
                 if want_fb:
                     out.setdefault("fb", torch.empty((n * k * NEIGH_BYTES,), dtype=torch.uint8, device=self.device))
+                if want_levels or allow_unfinished:
+                    out.setdefault("levels", torch.empty((n,), dtype=torch.int32, device=self.device))
             info = _lib.SolveInfo()
 
             def ptr(name):
                 t = out.get(name)
                 return ctypes.c_void_p(t.data_ptr()) if t is not None else None
 
-            _lib.check(self._lib.tknnSolve(self._h, int(k), ctypes.c_float(start_radius), int(kernel),
-                                           int(max_rounds), ptr("idx"), ptr("dist"), ptr("intersections"),
-                                           ptr("fb"), ctypes.byref(info), self._stream()))
+            opt = _lib.SolveOptions()
+            opt.k, opt.start_radius, opt.kernel = int(k), float(start_radius), int(kernel)
+            opt.max_rounds, opt.allow_unfinished = int(max_rounds), int(bool(allow_unfinished))
+            for field, name in (("d_idx", "idx"), ("d_dist", "dist"), ("d_intersections", "intersections"),
+                                ("d_fb", "fb"), ("d_levels", "levels")):
+                p = ptr(name)
+                setattr(opt, field, p.value if p is not None else None)
+            _lib.check(self._lib.tknnSolveEx(self._h, ctypes.byref(opt), ctypes.byref(info), self._stream()))
         self.last_info = info.as_dict()
         out["info"] = self.last_info
         return out

@@ -1,0 +1,87 @@
+"""Worker for the multi-rank tests: launched by torch.distributed.run (see test_distributed.py).
+
+    dist_worker.py <engine: checker|hip> <n_total> <k> <dataset> <out.npz>
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from owlraytracing_amd import datasets, distributed as tkd  # noqa: E402
+
+
+class CheckerEngine:
+    """Stand-in for owlraytracing_amd.trueknn.TrueKNN backed by the CPU checker's numpy restatement
+    (tests only): same build / set_halo / solve contract, tensors on the CPU."""
+
+    def __init__(self, device):
+        self.device = device
+        self.halo = (np.zeros((0, 3), np.float32), np.zeros(0, np.int32))
+
+    def build(self, points, ids=None):
+        self.pts = points.cpu().numpy()
+        self.ids = ids.cpu().numpy()
+        self.n = len(self.pts)
+
+    def set_halo(self, points=None, ids=None):
+        if points is None or len(points) == 0:
+            self.halo = (np.zeros((0, 3), np.float32), np.zeros(0, np.int32))
+        else:
+            self.halo = (points.cpu().numpy(), ids.cpu().numpy())
+
+    def solve(self, k, start_radius, kernel=0, max_rounds=64, want_fb=False, want_levels=False, allow_unfinished=False, out=None):
+        from oracle.trueknn_numpy import trueknn_numpy
+        xyz = np.concatenate([self.pts, self.halo[0]])
+        ids = np.concatenate([self.ids, self.halo[1]]).astype(np.int64)
+        r = trueknn_numpy(xyz, k, start_radius, max_rounds=max_rounds, query_ids=np.arange(self.n),
+                          stop_quietly=allow_unfinished, ids=ids)
+        lev = r["level"][: self.n]
+        info = {"rounds": int(lev.max()) + 1 if (lev >= 0).any() else r["rounds"], "unfinished": int((lev < 0).sum()),
+                "total_intersections": int(r["intersections"][: self.n][lev >= 0].sum()), "kernel_used": 0,
+                "dominant_kernel_ms": 0.0, "dominant_kernel_launches": 1, "node_tests": 0, "point_tests": 0,
+                "total_active_rounds": 0, "solve_ms": 0.0, "final_radius": r["final_radius"], "list_capacity": k}
+        return {"idx": torch.from_numpy(r["idx"][: self.n].astype(np.int32)),
+                "dist": torch.from_numpy(r["dist"][: self.n]),
+                "intersections": torch.from_numpy(r["intersections"][: self.n]),
+                "levels": torch.from_numpy(lev.astype(np.int32)), "info": info}
+
+
+def make_points(name, n):
+    if name == "uniform":
+        return datasets.uniform3d(n, seed=5)
+    if name == "clustered":
+        return datasets.gaussian_mixture3d(n, components=6, sigma=0.05, seed=6)
+    if name == "planar":
+        return datasets.pad_to_3d(datasets.taxi_like2d(n, components=8, seed=7))
+    raise ValueError(name)
+
+
+def main():
+    engine, n, k, name, out = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), sys.argv[4], sys.argv[5]
+    use_gpu = engine == "hip"
+    dist.init_process_group("gloo")  # host-staged messages: CPU ranks, or ranks sharing one GPU
+    rank, world = dist.get_rank(), dist.get_world_size()
+    dev = torch.device("cuda", 0) if use_gpu else torch.device("cpu")
+    if use_gpu:
+        torch.cuda.set_device(0)
+    pts = make_points(name, n)
+    lo, hi = n * rank // world, n * (rank + 1) // world  # arbitrary initial ownership: contiguous slices
+    solver = tkd.ShardedTrueKNN(dev, engine_factory=None if use_gpu else CheckerEngine, halo_levels=int(os.environ.get("HALO_LEVELS", "1")))
+    solver.load_points(torch.from_numpy(pts[lo:hi]), torch.arange(lo, hi, dtype=torch.int32))
+    r0 = float(os.environ.get("START_RADIUS", datasets.start_radius(n, k)))
+    info = solver.solve(k, r0)
+    gids, idx, dst, isect = solver.gather_rows()
+    if rank == 0:
+        np.savez(out, gids=gids, idx=idx, dist=dst, isect=isect, rounds=info["rounds"],
+                 exchanges=info["halo_exchanges"], halo_points=info["halo_points"], tile=len(solver.points))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

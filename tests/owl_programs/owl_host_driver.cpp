@@ -237,13 +237,13 @@ static int run_count(int argc, char **argv) {
   // out file: count[n] i32 | nearest[n] f32 | calls[n] i64 | first_hit[n] i32
   std::vector<char> out(n * (4 + 4 + 8 + 4));
   char *p = out.data();
-  cudaMemcpy(p, owlBufferGetPointer(count, 0), n * 4, cudaMemcpyDeviceToHost);
+  CUDA_CHECK(cudaMemcpy(p, owlBufferGetPointer(count, 0), n * 4, cudaMemcpyDeviceToHost));
   p += n * 4;
-  cudaMemcpy(p, owlBufferGetPointer(nearest, 0), n * 4, cudaMemcpyDeviceToHost);
+  CUDA_CHECK(cudaMemcpy(p, owlBufferGetPointer(nearest, 0), n * 4, cudaMemcpyDeviceToHost));
   p += n * 4;
-  cudaMemcpy(p, owlBufferGetPointer(calls, 0), n * 8, cudaMemcpyDeviceToHost);
+  CUDA_CHECK(cudaMemcpy(p, owlBufferGetPointer(calls, 0), n * 8, cudaMemcpyDeviceToHost));
   p += n * 8;
-  cudaMemcpy(p, owlBufferGetPointer(first, 0), n * 4, cudaMemcpyDeviceToHost);
+  CUDA_CHECK(cudaMemcpy(p, owlBufferGetPointer(first, 0), n * 4, cudaMemcpyDeviceToHost));
   write_file(argv[6], out.data(), out.size());
   std::printf("n0=%zu n1=%zu\n", n0, n1);
   owlContextDestroy(ctx);

@@ -1,0 +1,60 @@
+"""The sharded (Morton tiles + halo exchange) path against the single-process CPU checker."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import oracle
+from owlraytracing_amd import datasets
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+WORKER = os.path.join(ROOT, "tests", "dist_worker.py")
+
+
+def _run(engine, world, n, k, name, tmp_path, port, env_extra=None, timeout=600):
+    out = str(tmp_path / ("rows_%s_%d.npz" % (name, world)))
+    env = dict(os.environ)
+    env.update({"MASTER_ADDR": "127.0.0.1", "OMP_NUM_THREADS": "2"})
+    env.update(env_extra or {})
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), WORKER, engine, str(n), str(k), name, out]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env, cwd=ROOT)
+    assert r.returncode == 0, (r.stdout[-3000:] + r.stderr[-3000:])
+    return np.load(out)
+
+
+def _check(got, name, n, k, r0=None):
+    from dist_worker import make_points
+    pts = make_points(name, n)
+    ref = oracle.trueknn(pts, k, datasets.start_radius(n, k) if r0 is None else r0)
+    assert np.array_equal(got["gids"], np.arange(n))
+    assert np.array_equal(got["idx"], ref["idx"])
+    assert np.array_equal(got["dist"], ref["dist"])
+    assert np.array_equal(got["isect"], ref["intersections"])
+    assert int(got["rounds"]) == ref["rounds"]
+
+
+@pytest.mark.parametrize("world,name,n,k", [(2, "uniform", 3000, 5), (3, "clustered", 2500, 4), (2, "planar", 2000, 3)])
+def test_tiles_and_halo_exchange_reproduce_the_single_process_result(tmp_path, world, name, n, k):
+    """gloo, CPU ranks, checker-backed engine: partition, halo selection, straggler loop, global ids."""
+    got = _run("checker", world, n, k, name, tmp_path, 29611 + world)
+    _check(got, name, n, k)
+    assert int(got["halo_points"]) > 0
+
+
+def test_stragglers_force_a_wider_halo(tmp_path):
+    # a start radius far too small: the first halo (1 level) cannot serve the final radius level
+    got = _run("checker", 2, 1500, 6, "uniform", tmp_path, 29631, {"START_RADIUS": "0.004", "HALO_LEVELS": "1"})
+    _check(got, "uniform", 1500, 6, r0=0.004)
+    assert int(got["exchanges"]) > 1
+
+
+@pytest.mark.gpu
+def test_two_ranks_sharing_one_gpu_with_the_hip_engine(tmp_path):
+    """Real engine (ids, halo tree, allow_unfinished) under the sharded driver; messages host-staged
+    through gloo because both ranks sit on the one GPU of the box."""
+    n, k = 200_000, 10
+    got = _run("hip", 2, n, k, "uniform", tmp_path, 29641, {"HALO_LEVELS": "2"})
+    _check(got, "uniform", n, k)
