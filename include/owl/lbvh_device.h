@@ -35,6 +35,18 @@ struct LbvhBox { /* 24 bytes = owl::box3f, what a bounds program writes */
   float hi[3];
 };
 
+/* 64-ary box pyramid over fixed blocks of LBVH_BLOCK Morton-consecutive points ("wide" view of the
+ * same sorted order, one node = the 64 children a wave tests in one step):
+ *   level[0][b] = box of points [LBVH_BLOCK*b, LBVH_BLOCK*(b+1));  level[l][j] = box of
+ *   level[l-1][64j .. 64j+63];  the top level has <= 64 entries. */
+#define LBVH_BLOCK 16
+#define LBVH_WIDE_LEVELS 6
+struct LbvhWideView {
+  const LbvhBox *level[LBVH_WIDE_LEVELS];
+  int32_t count[LBVH_WIDE_LEVELS];
+  int32_t levels;
+};
+
 struct LbvhView {
   const LbvhNode *nodes;    /* n-1 */
   const int32_t *rope_node; /* n-1 */

@@ -10,7 +10,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libowl_mi355x.so")
 
-KERNEL_AUTO, KERNEL_LANE, KERNEL_WAVE = 0, 1, 2
+KERNEL_AUTO, KERNEL_LANE, KERNEL_WAVE, KERNEL_TEAM = 0, 1, 2, 3
 MAX_K = 64
 
 

@@ -46,6 +46,7 @@ class Lbvh {
   void refit_boxes(const LbvhBox *d_boxes, hipStream_t stream);
 
   LbvhView view() const;
+  LbvhWideView wide_view() const;  // point trees only
   int64_t size() const { return n_; }
   bool built() const { return built_; }
   bool has_points() const { return points_ != nullptr && point_mode_; }
@@ -77,6 +78,10 @@ class Lbvh {
   int32_t *prim_id_ = nullptr;
   LbvhBox *table_[4] = {nullptr, nullptr, nullptr, nullptr};
   int64_t table_n_[4] = {0, 0, 0, 0};
+  LbvhBox *wide_[LBVH_WIDE_LEVELS] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  int64_t wide_n_[LBVH_WIDE_LEVELS] = {0, 0, 0, 0, 0, 0};
+  int wide_levels_ = 0;
+  void build_wide(hipStream_t stream);
 };
 
 }  // namespace owlmi

@@ -147,7 +147,16 @@ __global__ void __launch_bounds__(kBlock) gather_kernel(const float *__restrict_
                                                        int32_t *__restrict__ prim_id,
                                                        const int32_t *__restrict__ ids) {
   int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-  if (i >= n) return;
+  if (i >= n) {
+    // sentinels fill the last leaf block: NaN coordinates fail every box comparison
+    if (POINTS && i < (n + LBVH_BLOCK - 1) / LBVH_BLOCK * LBVH_BLOCK) {
+      LbvhPoint s;
+      s.x = s.y = s.z = __uint_as_float(0x7fc00000u);
+      s.id = -1;
+      points[i] = s;
+    }
+    return;
+  }
   uint32_t src = order[i];
   prim_id[i] = (int32_t)src;
   if (POINTS) {
@@ -229,6 +238,28 @@ __global__ void __launch_bounds__(kBlock) table_kernel(const void *__restrict__ 
   }
 }
 
+// level 0 of the wide pyramid: one thread per block of LBVH_BLOCK sorted points
+__global__ void __launch_bounds__(kBlock) block_box_kernel(const LbvhPoint *__restrict__ pts, int64_t n,
+                                                          LbvhBox *__restrict__ out, int64_t n_out) {
+  int64_t b = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (b >= n_out) return;
+  Box6 box = empty_box();
+  for (int j = 0; j < LBVH_BLOCK; j++) {
+    int64_t i = b * LBVH_BLOCK + j;
+    if (i < n) {
+      LbvhPoint p = pts[i];
+      float c[3] = {p.x, p.y, p.z};
+      grow(box, c, c);
+    }
+  }
+  LbvhBox o;
+  for (int a = 0; a < 3; a++) {
+    o.lo[a] = box.lo[a];
+    o.hi[a] = box.hi[a];
+  }
+  out[b] = o;
+}
+
 struct Pyramid {
   const LbvhPoint *points;
   const LbvhBox *boxes;
@@ -302,6 +333,10 @@ void dev_alloc(T *&p, size_t count, size_t &total) {
 Lbvh::~Lbvh() { release(); }
 
 void Lbvh::release() {
+  for (auto &w : wide_) {
+    if (w) (void)hipFree(w);
+    w = nullptr;
+  }
   void *ptrs[] = {scene_, partials_, codes_, codes_alt_, order_, order_alt_, sort_tmp_, nodes_,
                   split_owner_, rope_node_, rope_leaf_, points_, boxes_, prim_id_, table_[0],
                   table_[1], table_[2], table_[3]};
@@ -341,7 +376,7 @@ void Lbvh::reserve(int64_t n) {
   dev_alloc(split_owner_, (size_t)n, total);
   dev_alloc(rope_node_, (size_t)n, total);
   dev_alloc(rope_leaf_, (size_t)n, total);
-  dev_alloc(points_, (size_t)n, total);
+  dev_alloc(points_, (size_t)n + LBVH_BLOCK, total);  // + NaN sentinels up to a whole leaf block
   dev_alloc(boxes_, (size_t)n, total);
   dev_alloc(prim_id_, (size_t)n, total);
   int64_t m = n;
@@ -349,8 +384,40 @@ void Lbvh::reserve(int64_t n) {
     m = (m + 63) / 64;
     dev_alloc(table_[l], (size_t)m, total);
   }
+  m = (n + LBVH_BLOCK - 1) / LBVH_BLOCK;
+  for (int l = 0; l < LBVH_WIDE_LEVELS; l++) {
+    dev_alloc(wide_[l], (size_t)m, total);
+    m = (m + 63) / 64;
+  }
   cap_ = n;
   bytes_ = total;
+}
+
+void Lbvh::build_wide(hipStream_t stream) {
+  int64_t m = (n_ + LBVH_BLOCK - 1) / LBVH_BLOCK;
+  wide_n_[0] = m;
+  hipLaunchKernelGGL(block_box_kernel, dim3(blocks_for(m)), dim3(kBlock), 0, stream, points_, n_, wide_[0], m);
+  OWLMI_HIP(hipGetLastError());
+  wide_levels_ = 1;
+  while (wide_n_[wide_levels_ - 1] > 64 && wide_levels_ < LBVH_WIDE_LEVELS) {
+    const int l = wide_levels_;
+    const int64_t in_n = wide_n_[l - 1], out_n = (in_n + 63) / 64;
+    wide_n_[l] = out_n;
+    hipLaunchKernelGGL(table_kernel<1>, dim3(blocks_for(out_n * 64)), dim3(kBlock), 0, stream,
+                       (const void *)wide_[l - 1], in_n, wide_[l], out_n);
+    OWLMI_HIP(hipGetLastError());
+    wide_levels_++;
+  }
+}
+
+LbvhWideView Lbvh::wide_view() const {
+  LbvhWideView w;
+  for (int l = 0; l < LBVH_WIDE_LEVELS; l++) {
+    w.level[l] = l < wide_levels_ ? wide_[l] : nullptr;
+    w.count[l] = l < wide_levels_ ? (int32_t)wide_n_[l] : 0;
+  }
+  w.levels = point_mode_ ? wide_levels_ : 0;
+  return w;
 }
 
 void Lbvh::sort_and_tree(hipStream_t stream) {
@@ -404,10 +471,11 @@ void Lbvh::build_from_points(const float *d_xyz, int64_t n, hipStream_t stream, 
                      (const LbvhBox *)nullptr, n, scene_, codes_, order_);
   OWLMI_HIP(hipGetLastError());
   sort_and_tree(stream);
-  hipLaunchKernelGGL(gather_kernel<true>, dim3(blocks_for(n)), dim3(kBlock), 0, stream, d_xyz,
+  hipLaunchKernelGGL(gather_kernel<true>, dim3(blocks_for(n + LBVH_BLOCK)), dim3(kBlock), 0, stream, d_xyz,
                      (const LbvhBox *)nullptr, n, order_alt_, points_, (LbvhBox *)nullptr, prim_id_, d_ids);
   OWLMI_HIP(hipGetLastError());
   fit(stream);
+  build_wide(stream);
   built_ = true;
 }
 

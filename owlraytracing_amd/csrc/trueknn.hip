@@ -28,6 +28,7 @@ struct LaneRoundArgs {
   float radius;
   int k;
   uint8_t *done;           // per sorted slot
+  const int32_t *next_level;  // per sorted slot: first level this query takes part in (may be null)
   int64_t *isect_sorted;   // per sorted slot, accumulated over rounds
   int32_t *out_idx;        // n*k, caller order (may be null)
   float *out_dist;         // n*k (may be null)
@@ -71,7 +72,7 @@ __global__ void __launch_bounds__(kLaneBlock) lane_round_kernel(LaneRoundArgs a)
   const LbvhView &bvh = a.bvh;
   // deviceCode.cu:148: finished queries launch no ray.  Inactive lanes fall through to the
   // wave-wide counter reduction at the end instead of returning.
-  const bool active = t < bvh.n && !a.done[t];
+  const bool active = t < bvh.n && !a.done[t] && (!a.next_level || a.next_level[t] <= a.level);
   LbvhPoint q = {0.f, 0.f, 0.f, -1};
   if (active) q = bvh.points[t];
   const float r = a.radius;
@@ -120,7 +121,8 @@ __global__ void __launch_bounds__(kLaneBlock) lane_round_kernel(LaneRoundArgs a)
     }
   }
   // wave-aggregated counters (all 64 lanes are here)
-  unsigned long long unfinished = __popcll(__ballot(active && !finished));
+  const bool waiting = t < bvh.n && !a.done[t] && !active;  // handed over at a later level
+  unsigned long long unfinished = __popcll(__ballot((active && !finished) || waiting));
   unsigned long long traced = __popcll(__ballot(active));
   unsigned long long nt = node_tests, pt = point_tests, si = finished ? (unsigned long long)isect : 0ull;
 #pragma unroll
@@ -168,6 +170,7 @@ Engine::Engine() {
 Engine::~Engine() {
   if (done_) (void)hipFree(done_);
   if (isect_sorted_) (void)hipFree(isect_sorted_);
+  if (next_level_) (void)hipFree(next_level_);
   if (counters_) (void)hipFree(counters_);
   if (h_counters_) (void)hipHostFree(h_counters_);
   if (wave_ws_) (void)hipFree(wave_ws_);
@@ -198,10 +201,13 @@ void Engine::build(const float *d_xyz, const int32_t *d_ids, int64_t n, tknnBuil
   if (n > state_cap_) {
     if (done_) (void)hipFree(done_);
     if (isect_sorted_) (void)hipFree(isect_sorted_);
+    if (next_level_) (void)hipFree(next_level_);
     done_ = nullptr;
     isect_sorted_ = nullptr;
+    next_level_ = nullptr;
     OWLMI_HIP(hipMalloc((void **)&done_, (size_t)n));
     OWLMI_HIP(hipMalloc((void **)&isect_sorted_, (size_t)n * sizeof(int64_t)));
+    OWLMI_HIP(hipMalloc((void **)&next_level_, (size_t)n * sizeof(int32_t)));
     state_cap_ = n;
   }
   OWLMI_HIP(hipEventSynchronize(ev_b_));
@@ -214,13 +220,21 @@ void Engine::build(const float *d_xyz, const int32_t *d_ids, int64_t n, tknnBuil
   }
 }
 
-void Engine::solve_lane(const SolveArgs &sa, tknnSolveInfo *info, hipStream_t s) {
+void Engine::solve_lane(const SolveArgs &sa, tknnSolveInfo *info, hipStream_t s) { lane_rounds(sa, 0, true, info, s); }
+
+void Engine::continue_lane(const SolveArgs &sa, int first_level, tknnSolveInfo *info, hipStream_t s) {
+  lane_rounds(sa, first_level, false, info, s);
+}
+
+void Engine::lane_rounds(const SolveArgs &sa, int first_level, bool fresh, tknnSolveInfo *info, hipStream_t s) {
   const int64_t n = bvh_.size();
   const int cap = list_capacity_for(sa.k);
-  OWLMI_HIP(hipMemsetAsync(done_, 0, (size_t)n, s));
-  OWLMI_HIP(hipMemsetAsync(isect_sorted_, 0, (size_t)n * sizeof(int64_t), s));
+  if (fresh) {
+    OWLMI_HIP(hipMemsetAsync(done_, 0, (size_t)n, s));
+    OWLMI_HIP(hipMemsetAsync(isect_sorted_, 0, (size_t)n * sizeof(int64_t), s));
+    if (sa.d_levels) OWLMI_HIP(hipMemsetAsync(sa.d_levels, 0xff, (size_t)n * sizeof(int32_t), s));
+  }
   OWLMI_HIP(hipMemsetAsync(counters_, 0, 16 * sizeof(unsigned long long), s));
-  if (sa.d_levels) OWLMI_HIP(hipMemsetAsync(sa.d_levels, 0xff, (size_t)n * sizeof(int32_t), s));
   LaneRoundArgs a;
   a.bvh = bvh_.view();
   a.halo = halo_view();
@@ -228,13 +242,15 @@ void Engine::solve_lane(const SolveArgs &sa, tknnSolveInfo *info, hipStream_t s)
   a.k = sa.k;
   a.done = done_;
   a.isect_sorted = isect_sorted_;
+  a.next_level = fresh ? nullptr : next_level_;
   a.out_idx = sa.d_idx;
   a.out_dist = sa.d_dist;
   a.out_isect = sa.d_isect;
   a.out_fb = sa.d_fb;
   a.counters = counters_;
   float radius = sa.start_radius, total_ms = 0;
-  int rounds = 0;
+  int rounds = first_level, launches = 0;
+  for (int t = 0; t < first_level; t++) radius *= 2;
   for (;;) {
     if (rounds >= sa.max_rounds) {
       if (sa.allow_unfinished) break;
@@ -242,6 +258,7 @@ void Engine::solve_lane(const SolveArgs &sa, tknnSolveInfo *info, hipStream_t s)
     }
     a.level = rounds;
     rounds++;
+    launches++;
     a.radius = radius;
     OWLMI_HIP(hipMemsetAsync(counters_, 0, sizeof(unsigned long long), s));  // [0] only
     OWLMI_HIP(hipEventRecord(ev_a_, s));
@@ -277,8 +294,8 @@ void Engine::solve_lane(const SolveArgs &sa, tknnSolveInfo *info, hipStream_t s)
     info->total_intersections = (int64_t)h_counters_[3];
     info->total_active_rounds = (int64_t)h_counters_[4];
     info->solve_ms = total_ms;
-    info->dominant_kernel_ms = total_ms / rounds;
-    info->dominant_kernel_launches = rounds;
+    info->dominant_kernel_ms = total_ms / std::max(launches, 1);
+    info->dominant_kernel_launches = launches;
     info->kernel_used = TKNN_KERNEL_LANE;
     info->list_capacity = cap;
     info->unfinished = (int64_t)h_counters_[0];
@@ -286,7 +303,14 @@ void Engine::solve_lane(const SolveArgs &sa, tknnSolveInfo *info, hipStream_t s)
 }
 
 void Engine::solve(const SolveArgs &sa, int kernel, tknnSolveInfo *info, hipStream_t s) {
-  if (kernel == TKNN_KERNEL_AUTO) kernel = wave_kernel_available() ? TKNN_KERNEL_WAVE : TKNN_KERNEL_LANE;
+  if (kernel == TKNN_KERNEL_TEAM && !team_kernel_supports(sa.k))
+    throw ArgError{TKNN_E_UNSUPPORTED, "the team kernel holds one neighbour per lane of a 16-lane team: k <= 16"};
+  if (kernel == TKNN_KERNEL_AUTO)
+    kernel = team_kernel_supports(sa.k) ? TKNN_KERNEL_TEAM : (wave_kernel_available() ? TKNN_KERNEL_WAVE : TKNN_KERNEL_LANE);
+  if (kernel == TKNN_KERNEL_TEAM) {
+    if (solve_team(sa, info, s)) return;
+    kernel = TKNN_KERNEL_WAVE;  // candidate sets too large for the team kernel's block masks
+  }
   if (kernel == TKNN_KERNEL_WAVE)
     solve_wave(sa, info, s);
   else
@@ -410,7 +434,8 @@ int tknnSolveEx(tknnEngine e, const tknnSolveOptions *options, tknnSolveInfo *in
       throw owlmi::ArgError{TKNN_E_ARG, "tknnSolve: need n > k (the reference never terminates otherwise)"};
     if (!(start_radius > 0.f) || !std::isfinite(start_radius))
       throw owlmi::ArgError{TKNN_E_ARG, "tknnSolve: start_radius must be finite and > 0"};
-    if (kernel != TKNN_KERNEL_AUTO && kernel != TKNN_KERNEL_LANE && kernel != TKNN_KERNEL_WAVE)
+    if (kernel != TKNN_KERNEL_AUTO && kernel != TKNN_KERNEL_LANE && kernel != TKNN_KERNEL_WAVE &&
+        kernel != TKNN_KERNEL_TEAM)
       throw owlmi::ArgError{TKNN_E_ARG, "tknnSolve: unknown kernel selector"};
     owlmi::SolveArgs sa;
     sa.k = k;

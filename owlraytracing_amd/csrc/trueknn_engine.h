@@ -52,8 +52,14 @@ class Engine {
 
  private:
   void solve_lane(const SolveArgs &sa, tknnSolveInfo *info, hipStream_t s);
+  // lane rounds over the queries another kernel left with done_[slot] == 0, each from next_level_[slot]
+  void continue_lane(const SolveArgs &sa, int first_level, tknnSolveInfo *info, hipStream_t s);
+  void lane_rounds(const SolveArgs &sa, int first_level, bool fresh, tknnSolveInfo *info, hipStream_t s);
   void solve_wave(const SolveArgs &sa, tknnSolveInfo *info, hipStream_t s);  // trueknn_wave.hip
   static bool wave_kernel_available();                                        // trueknn_wave.hip
+  // trueknn_team.hip; returns false if a packet needed more leaf blocks than the kernel can name
+  bool solve_team(const SolveArgs &sa, tknnSolveInfo *info, hipStream_t s);
+  static bool team_kernel_supports(int k);
 
   int device_ = 0;
   Lbvh bvh_;
@@ -61,6 +67,7 @@ class Engine {
   int64_t halo_n_ = 0;
   uint8_t *done_ = nullptr;
   int64_t *isect_sorted_ = nullptr;
+  int32_t *next_level_ = nullptr;
   int64_t state_cap_ = 0;
   unsigned long long *counters_ = nullptr, *h_counters_ = nullptr;
   void *wave_ws_ = nullptr;

@@ -1,0 +1,652 @@
+// trueknn_team.hip -- the team TrueKNN kernel (TKNN_KERNEL_TEAM), k <= 16.
+//
+// The wave-packet kernel (trueknn_wave.hip) broadcasts every candidate of a 64-query packet to all
+// 64 lanes; on MI355X it is VALU-issue-bound with ~2.5 % useful lanes (profiles/r01_wave_v2_*),
+// because the packet's candidate union is ~40x one query's own box content.  This kernel turns
+// the work around: a wave is FOUR TEAMS OF 16 LANES; a team handles one query at a time and its
+// lanes are the 16 CANDIDATES of one leaf block (LBVH_BLOCK consecutive Morton-sorted points,
+// one coalesced 256-byte read) of that query's OWN block list.
+//
+// Per packet of 64 Morton-consecutive queries and per radius level (hostCode.cpp:285-340 rounds):
+//   1. lanes = queries: exact candidate thresholds (as in the wave kernel) -> LDS query records.
+//   2. lanes = child boxes: the wave walks the 64-ary block pyramid (LbvhWideView) depth-first
+//      with an LDS stack, one wide node per step, against the union box of the packet.
+//   3. every surviving leaf block is tested against the 64 individual query boxes
+//      (lanes = queries again, block box broadcast by v_readlane); blocks some query needs are
+//      appended to the packet's block list and recorded in per-query bit masks (ballot, no atomics).
+//   4. COUNT pass, teams over the compacted list of active queries: count candidates in the
+//      query's box (deviceCode.cu:74) and those other than the query itself (:103).
+//   5. queries with >= k others are finished at this level (deviceCode.cu:118): SELECT pass,
+//      teams over the compacted list of finishing queries: distances, gate, and a team-parallel
+//      sorted insert -- lane j of the team holds the j-th best (dist,index) key; a new key is
+//      broadcast to the team and every lane decides locally whether it keeps, takes the key, or
+//      takes its left neighbour's entry (DPP row shift).  Rows are written straight from the
+//      team: lane j stores neighbour j (coalesced 4*k bytes per array).
+// Results are bit-identical to the other kernels: same thresholds, same distance arithmetic, keys
+// ordered by (dist, index).
+#include "trueknn_engine.h"
+
+#include <algorithm>
+#include <cstring>
+
+namespace owlmi {
+
+namespace {
+
+constexpr int kTeamBlock = 256;     // 4 independent waves per workgroup
+constexpr int kMaxBlocks = 256;     // leaf blocks one packet may need per level (slot fits a byte)
+constexpr int kMaxPerQuery = 96;    // leaf blocks one query may need per level
+constexpr int kTeamStack = 256;     // wide-pyramid stack entries per wave
+constexpr int kQrecStride = 12;     // floats per LDS query record
+// LDS per wave: query records | block list | per-query block lists | counts | query list | stack
+constexpr int kLdsQrec = 64 * kQrecStride * 4;
+constexpr int kLdsBlk = kMaxBlocks * 4;
+constexpr int kLdsMask = 64 * kMaxPerQuery;  // per-query lists of block slots (bytes)
+constexpr int kLdsCnt = 64 * 2 * 4 + 64 * 8;  // {cnt, others} per query + isect before this level
+constexpr int kLdsList = 64 * 4;
+constexpr int kLdsStack = kTeamStack * 4;
+constexpr int kTeamLds = kLdsQrec + kLdsBlk + kLdsMask + kLdsCnt + kLdsList + kLdsStack;
+
+struct TeamArgs {
+  LbvhView bvh, halo;
+  LbvhWideView wide[2];
+  float start_radius;
+  int k;
+  int max_rounds;
+  int allow_unfinished;
+  int32_t ngroups;
+  int32_t *out_idx;
+  float *out_dist;
+  int64_t *out_isect;
+  tknnNeigh *out_fb;
+  int32_t *out_level;
+  // continuation state for queries whose candidate lists outgrow the LDS lists (finished by the
+  // lane kernel): per sorted slot, preset by the host to done=1
+  uint8_t *done;
+  int64_t *isect_sorted;
+  int32_t *next_level;
+  // [0] packet counter [1] max levels [2] node tests [3] point tests [4] sum isect
+  // [5] error flags (1 max_rounds) [6] sum levels [7] unfinished [8] handed over [9] min hand-over level
+  unsigned long long *counters;
+};
+
+__device__ __forceinline__ void t_wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+__device__ __forceinline__ float t_bcast(float v, int lane) {
+  return __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(v), lane));
+}
+__device__ __forceinline__ float t_wave_min(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = fminf(v, __shfl_xor(v, off));
+  return v;
+}
+__device__ __forceinline__ float t_wave_max(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off));
+  return v;
+}
+__device__ __forceinline__ unsigned long long t_wave_sum(unsigned long long v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+  return v;
+}
+__device__ __forceinline__ int t_rank(unsigned long long mask) {
+  return __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+}
+// value of lane `src` (any lane of the wave, may differ per lane) -- LDS crossbar, no LDS memory
+__device__ __forceinline__ uint32_t t_lane_read(uint32_t v, int src) {
+  return (uint32_t)__builtin_amdgcn_ds_bpermute(src << 2, (int)v);
+}
+// sum over the 16 lanes of my team (row), result in every lane of the team
+__device__ __forceinline__ uint32_t t_team_sum(uint32_t v) {
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x128 /*row_ror:8*/, 0xf, 0xf, false);
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x124 /*row_ror:4*/, 0xf, 0xf, false);
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x122 /*row_ror:2*/, 0xf, 0xf, false);
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x121 /*row_ror:1*/, 0xf, 0xf, false);
+  return v;
+}
+// my left neighbour's value inside the team (lane 0 of a team gets `fill`)
+__device__ __forceinline__ uint32_t t_team_shr1(uint32_t v, uint32_t fill) {
+  return (uint32_t)__builtin_amdgcn_update_dpp((int)fill, (int)v, 0x111 /*row_shr:1*/, 0xf, 0xf, false);
+}
+
+// thresholds: shared with the wave kernel (exact equivalents of fl(c - r) <= q <= fl(c + r))
+__device__ __forceinline__ uint32_t tf_ord(float f) {
+  uint32_t b = __float_as_uint(f);
+  return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__device__ __forceinline__ float tf_unord(uint32_t u) {
+  return __uint_as_float((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u);
+}
+#define T_ORD_NEG_INF 0x007fffffu
+#define T_ORD_POS_INF 0xff800000u
+template <typename P>
+__device__ __forceinline__ uint32_t t_first_true(P pred, float guess) {
+  uint32_t u = tf_ord(guess);
+  u = u < T_ORD_NEG_INF ? T_ORD_NEG_INF : (u > T_ORD_POS_INF ? T_ORD_POS_INF : u);
+  uint32_t lo, hi;
+  if (pred(tf_unord(u))) {
+    hi = u;
+    uint32_t step = 1;
+    for (;;) {
+      uint32_t room = hi - T_ORD_NEG_INF;
+      if (room == 0) return hi;
+      uint32_t s = step < room ? step : room;
+      uint32_t t = hi - s;
+      if (pred(tf_unord(t))) {
+        if (t == T_ORD_NEG_INF) return t;
+        hi = t;
+        step <<= 1;
+      } else {
+        lo = t;
+        break;
+      }
+    }
+  } else {
+    lo = u;
+    uint32_t step = 1;
+    for (;;) {
+      uint32_t room = T_ORD_POS_INF - lo;
+      if (room == 0) return T_ORD_POS_INF + 1u;
+      uint32_t s = step < room ? step : room;
+      uint32_t t = lo + s;
+      if (pred(tf_unord(t))) {
+        hi = t;
+        break;
+      }
+      lo = t;
+      step <<= 1;
+    }
+  }
+  while (hi - lo > 1u) {
+    uint32_t mid = lo + ((hi - lo) >> 1);
+    if (pred(tf_unord(mid)))
+      hi = mid;
+    else
+      lo = mid;
+  }
+  return hi;
+}
+__device__ __forceinline__ float t_thr_lo(float q, float r) {
+#pragma clang fp contract(off)
+  if (!(q == q)) return INFINITY;
+  uint32_t key = t_first_true([=](float c) { return q <= c + r; }, q - r);
+  return key > T_ORD_POS_INF ? INFINITY : tf_unord(key);
+}
+__device__ __forceinline__ float t_thr_hi(float q, float r) {
+#pragma clang fp contract(off)
+  if (!(q == q)) return -INFINITY;
+  uint32_t key = t_first_true([=](float c) { return !(c - r <= q); }, q + r);
+  if (key <= T_ORD_NEG_INF) return -INFINITY;
+  return tf_unord(key - 1u);
+}
+__device__ __forceinline__ float t_gate(float w) {
+#pragma clang fp contract(off)
+  float w2 = w * w;
+  return w2 * 1.00000048f;
+}
+
+// one leaf block = LBVH_BLOCK sorted points, 16 bytes each; lane tl of a team reads point tl.
+// The sorted arrays are padded with NaN sentinels to whole blocks (lbvh.hip), so no bounds test.
+template <bool HALO>
+__device__ __forceinline__ LbvhPoint load_block_point(const LbvhPoint *own, const LbvhPoint *halo, int32_t entry) {
+  const LbvhPoint *base = (HALO && entry < 0) ? halo : own;
+  return base[(int64_t)(entry & 0x7fffffff) * LBVH_BLOCK];
+}
+
+struct TeamLds {
+  float *qrec;        // [64][kQrecStride]
+  int32_t *blk;       // [kMaxBlocks] block entries of the packet (bit 31: halo tree)
+  uint8_t *qblk;      // [64][kMaxPerQuery] per-query slots into blk[]
+  uint32_t *qcnt;     // [64][2] out: candidates in box, others
+  uint64_t *qis;      // [64] intersections accumulated before this level
+  int32_t *qlist;     // compact list of the queries this pass serves
+};
+
+// One pass of the four teams over a compact list of queries.  SELECT = false: count candidates
+// (deviceCode.cu:74,103).  SELECT = true: also keep the k best (dist,index) keys, lane j of the
+// team holding the j-th, and write the row if the query turns out finished (>= k others).
+template <bool SELECT, bool HALO>
+__device__ __forceinline__ void team_pass(const TeamArgs &a, const TeamLds &L, int n_list, int level,
+                                          const LbvhPoint *own_pts, const LbvhPoint *halo_pts, int lane) {
+  const int team = lane >> 4, tl = lane & 15;
+  const float qnan = __uint_as_float(0x7fc00000u);
+  for (int r0 = 0; r0 < n_list; r0 += 4) {
+    const bool on = r0 + team < n_list;
+    int qi = 0;
+    if (on) qi = L.qlist[r0 + team];
+    const float *rec = L.qrec + qi * kQrecStride;
+    const float t_qx = rec[0], t_qy = rec[1], t_qz = rec[2];
+    const int32_t t_qid = __float_as_int(rec[3]);
+    const float t_lx = rec[4], t_ly = rec[5], t_lz = rec[6], t_hx = rec[7], t_hy = rec[8], t_hz = rec[9];
+    const int my_n = on ? __float_as_int(rec[11]) : 0;  // leaf blocks of my team's query
+    int steps = my_n;                                   // wave-uniform trip count: longest list of the 4 teams
+    steps = max(steps, (int)__builtin_amdgcn_readlane(my_n, 16));
+    steps = max(steps, (int)__builtin_amdgcn_readlane(my_n, 32));
+    steps = max(steps, (int)__builtin_amdgcn_readlane(my_n, 48));
+    steps = max((int)__builtin_amdgcn_readlane(my_n, 0), steps);
+    // my query's block entries, spread over the team's lanes: lane tl holds entries tl, tl+16, ...
+    // (clamped to the last one; teams without a query read block 0 of the own tree and ignore it)
+    const uint8_t *mine = L.qblk + qi * kMaxPerQuery;
+    const int last = my_n - 1;
+    static_assert(kMaxPerQuery == 96, "entry registers below are written out for 6 x 16 entries");
+    int32_t e0 = 0, e1 = 0, e2 = 0, e3 = 0, e4 = 0, e5 = 0;  // named, not an array: must stay in VGPRs
+    if (my_n > 0) {
+      e0 = L.blk[mine[min(tl, last)]];
+      if (last >= 16) e1 = L.blk[mine[min(tl + 16, last)]];
+      if (last >= 32) e2 = L.blk[mine[min(tl + 32, last)]];
+      if (last >= 48) e3 = L.blk[mine[min(tl + 48, last)]];
+      if (last >= 64) e4 = L.blk[mine[min(tl + 64, last)]];
+      if (last >= 80) e5 = L.blk[mine[min(tl + 80, last)]];
+    }
+    auto entry_at = [&](int it) -> int32_t {  // `it` is wave-uniform
+      const int c = it < kMaxPerQuery ? it : kMaxPerQuery - 1;
+      const int j = c >> 4;
+      const int32_t v = j == 0 ? e0 : (j == 1 ? e1 : (j == 2 ? e2 : (j == 3 ? e3 : (j == 4 ? e4 : e5))));
+      return (int32_t)t_lane_read((uint32_t)v, (team << 4) + (c & 15));
+    };
+    uint32_t cnt = 0, self = 0;
+    uint32_t best_d = 0x7f7fffffu, best_i = 0u;  // KNN_EMPTY_KEY = {FLT_MAX, 0}
+    float tau2 = INFINITY;
+    // two blocks in flight ahead of the one being tested; loads are unconditional so the compiler
+    // can wait with a counted vmcnt instead of draining
+    LbvhPoint pa = load_block_point<HALO>(own_pts, halo_pts, entry_at(0));
+    LbvhPoint pb = load_block_point<HALO>(own_pts, halo_pts, entry_at(1));
+    for (int it = 0; it < steps; it++) {
+      const LbvhPoint pc = load_block_point<HALO>(own_pts, halo_pts, entry_at(it + 2));
+      LbvhPoint p = pa;
+      if (it >= my_n) p.x = qnan;  // past the end of my list (or no query): fails every comparison
+      const bool in = (t_lx <= p.x) && (p.x <= t_hx) && (t_ly <= p.y) && (p.y <= t_hy) && (t_lz <= p.z) && (p.z <= t_hz);
+      const bool is_self = in && (p.id == t_qid);  // ids are unique and a query lies in its own box
+      cnt += in ? 1u : 0u;
+      self += is_self ? 1u : 0u;
+      if (SELECT) {
+        const float d2 = knn_dist2(p.x, p.y, p.z, t_qx, t_qy, t_qz);
+        bool pend = in && !is_self && (d2 <= tau2);
+        unsigned long long pm = __ballot(pend);
+        if (pm) {
+          // exact key of my candidate, then one team-parallel sorted insert per pending lane
+          const uint32_t key_d = __float_as_uint(knn_sqrt(d2));
+          const uint32_t key_i = (uint32_t)p.id;
+          do {
+            const uint32_t pending_mine = (uint32_t)(pm >> (team * 16)) & 0xffffu;  // pending lanes of my team
+            const bool has = pending_mine != 0u;
+            const int src = (team << 4) + (has ? __ffs((int)pending_mine) - 1 : 0);
+            uint32_t cd = t_lane_read(key_d, src), ci = t_lane_read(key_i, src);
+            if (!has) {  // nothing to insert for this team in this step: a key that changes nothing
+              cd = 0xffffffffu;
+              ci = 0xffffffffu;
+            }
+            const uint64_t c = ((uint64_t)cd << 32) | ci;
+            const uint64_t cur = ((uint64_t)best_d << 32) | best_i;
+            const uint32_t pd = t_team_shr1(best_d, 0u), pi = t_team_shr1(best_i, 0u);
+            const uint64_t prev = ((uint64_t)pd << 32) | pi;  // lane 0: key 0, never greater than c
+            const bool take_prev = (tl != 0) && (c < prev);
+            const bool take_c = c < cur;
+            const uint64_t nw = take_prev ? prev : (take_c ? c : cur);
+            best_d = (uint32_t)(nw >> 32);
+            best_i = (uint32_t)nw;
+            if (lane == src) pend = false;
+            pm = __ballot(pend);
+          } while (pm);
+          // gate from the k-th best of my team
+          const float w = __uint_as_float(t_lane_read(best_d, (team << 4) + a.k - 1));
+          tau2 = t_gate(w);
+        }
+      }
+      pa = pb;
+      pb = pc;
+    }
+    cnt = t_team_sum(cnt);
+    self = t_team_sum(self);
+    const uint32_t others = cnt - self;
+    if (on && tl == 0) {
+      L.qcnt[qi * 2 + 0] = cnt;
+      L.qcnt[qi * 2 + 1] = others;
+    }
+    if (SELECT) {
+      // finished at this level (deviceCode.cu:118: k insertions happened): lane j < k stores neighbour j
+      if (on && others >= (uint32_t)a.k && tl < a.k) {
+        const int32_t out_row = __float_as_int(rec[10]);
+        const int64_t o = (int64_t)out_row * a.k + tl;
+        const uint64_t key = ((uint64_t)best_d << 32) | best_i;
+        const int32_t prim = knn_key_prim(key);
+        const float d = __uint_as_float(best_d);
+        if (a.out_idx) a.out_idx[o] = prim;
+        if (a.out_dist) a.out_dist[o] = d;
+        const int64_t tot = (int64_t)(L.qis[qi] + cnt);
+        if (a.out_fb) {
+          tknnNeigh ev;
+          ev.ind = prim;
+          ev.dist = d;
+          ev.numNeighbors = tl == 0 ? 0 : a.k;
+          ev.pad_ = 0;
+          ev.intersections = tl == 0 ? tot : 0;
+          a.out_fb[o] = ev;
+        }
+        if (tl == 0) {
+          if (a.out_isect) a.out_isect[out_row] = tot;
+          if (a.out_level) a.out_level[out_row] = level;
+        }
+      }
+    }
+  }
+}
+
+template <bool HALO>
+__global__ void __launch_bounds__(kTeamBlock) team_kernel(TeamArgs a) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  const int lane = threadIdx.x & 63;
+  const int wid = threadIdx.x >> 6;
+  const int tl = lane & 15;
+  unsigned char *base = smem + wid * kTeamLds;
+  float *qrec = (float *)base;
+  int32_t *blk = (int32_t *)(base + kLdsQrec);
+  uint8_t *qblk = (uint8_t *)(base + kLdsQrec + kLdsBlk);  // [query][kMaxPerQuery] slots into blk[]
+  uint32_t *qcnt = (uint32_t *)(base + kLdsQrec + kLdsBlk + kLdsMask);
+  uint64_t *qis = (uint64_t *)(base + kLdsQrec + kLdsBlk + kLdsMask + 64 * 2 * 4);
+  int32_t *qlist = (int32_t *)(base + kLdsQrec + kLdsBlk + kLdsMask + kLdsCnt);
+  int32_t *stack = (int32_t *)(base + kLdsQrec + kLdsBlk + kLdsMask + kLdsCnt + kLdsList);
+
+  const LbvhPoint *own_pts = a.bvh.points + tl, *halo_pts = a.halo.points ? a.halo.points + tl : a.bvh.points + tl;
+  unsigned long long my_isect_sum = 0, my_levels = 0, my_unfinished = 0, wave_node_tests = 0, wave_point_tests = 0;
+  int wave_levels = 0, wave_err = 0;
+  unsigned long long my_handed = 0;
+  int wave_min_handover = 0x7fffffff;
+
+  for (;;) {
+    int g = 0;
+    if (lane == 0) g = (int)atomicAdd(&a.counters[0], 1ull);
+    g = __builtin_amdgcn_readfirstlane(g);
+    if (g >= a.ngroups || wave_err) break;
+
+    const int32_t slot = g * 64 + lane;
+    bool active = slot < a.bvh.n;
+    LbvhPoint q = {0.f, 0.f, 0.f, -1};
+    if (active) q = a.bvh.points[slot];
+    const int32_t row = active ? a.bvh.prim_id[slot] : 0;
+    float r = a.start_radius;
+    int level = 0;
+    int64_t isect = 0;
+    uint32_t prev_others = 0;  // others in my box at the previous level
+    TeamLds L;
+    L.qrec = qrec;
+    L.blk = blk;
+    L.qblk = qblk;
+    L.qcnt = qcnt;
+    L.qis = qis;
+    L.qlist = qlist;
+
+    for (;;) {  // radius levels
+      // ---- 1. thresholds, query records ----------------------------------------------------
+      float lo_x = INFINITY, lo_y = INFINITY, lo_z = INFINITY, hi_x = -INFINITY, hi_y = -INFINITY, hi_z = -INFINITY;
+      if (active) {
+        lo_x = t_thr_lo(q.x, r);
+        lo_y = t_thr_lo(q.y, r);
+        lo_z = t_thr_lo(q.z, r);
+        hi_x = t_thr_hi(q.x, r);
+        hi_y = t_thr_hi(q.y, r);
+        hi_z = t_thr_hi(q.z, r);
+      }
+      const float g_lo_x = t_wave_min(lo_x), g_lo_y = t_wave_min(lo_y), g_lo_z = t_wave_min(lo_z);
+      const float g_hi_x = t_wave_max(hi_x), g_hi_y = t_wave_max(hi_y), g_hi_z = t_wave_max(hi_z);
+      {
+        float *rec = qrec + lane * kQrecStride;
+        rec[0] = q.x;
+        rec[1] = q.y;
+        rec[2] = q.z;
+        rec[3] = __int_as_float(q.id);
+        rec[4] = lo_x;
+        rec[5] = lo_y;
+        rec[6] = lo_z;
+        rec[7] = hi_x;
+        rec[8] = hi_y;
+        rec[9] = hi_z;
+      }
+
+      // ---- 2+3. gather the packet's block list and the per-query masks ----------------------
+      int my_nblk = 0;  // lane = query: how many blocks of the packet's list I need
+      int nb = 0;
+      bool too_big = false;  // this packet-level does not fit the LDS lists
+      for (int tree = 0; tree < 2 && !too_big; tree++) {
+        const LbvhWideView &wv = a.wide[tree];
+        const int32_t tree_n = tree == 0 ? a.bvh.n : a.halo.n;
+        if (tree_n <= 0 || wv.levels <= 0) continue;
+        int sp = 1;
+        if (lane == 0) stack[0] = (wv.levels << 26) | 0;  // virtual root above the top level
+        t_wave_sync();
+        while (sp > 0 && !too_big) {
+          const int32_t e = __builtin_amdgcn_readfirstlane(stack[sp - 1]);  // same address in every lane
+          sp--;
+          const int lvl = (e >> 26) - 1;    // level of the children
+          const int32_t first_child = (e & 0x3ffffff) * 64;
+          const int32_t c = first_child + lane;
+          const bool valid = lvl == wv.levels - 1 ? (lane < wv.count[lvl] && first_child == 0) : (c < wv.count[lvl]);
+          LbvhBox bx = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
+          if (valid) bx = wv.level[lvl][c];
+          wave_node_tests += 64;
+          const bool ov = valid & (bx.lo[0] <= g_hi_x) & (bx.hi[0] >= g_lo_x) & (bx.lo[1] <= g_hi_y) &
+                          (bx.hi[1] >= g_lo_y) & (bx.lo[2] <= g_hi_z) & (bx.hi[2] >= g_lo_z);
+          unsigned long long om = __ballot(ov);
+          if (lvl > 0) {
+            if (sp + __popcll(om) > kTeamStack) {
+              too_big = true;
+              break;
+            }
+            if (ov) stack[sp + t_rank(om)] = ((lvl) << 26) | c;
+            sp += __popcll(om);
+            t_wave_sync();
+          } else {
+            // leaf blocks: which of my 64 queries need block c?
+            while (om) {
+              const int src = __ffsll((long long)om) - 1;
+              om &= om - 1;
+              const float b_lo_x = t_bcast(bx.lo[0], src), b_lo_y = t_bcast(bx.lo[1], src), b_lo_z = t_bcast(bx.lo[2], src);
+              const float b_hi_x = t_bcast(bx.hi[0], src), b_hi_y = t_bcast(bx.hi[1], src), b_hi_z = t_bcast(bx.hi[2], src);
+              const bool need = (b_lo_x <= hi_x) & (b_hi_x >= lo_x) & (b_lo_y <= hi_y) & (b_hi_y >= lo_y) &
+                                (b_lo_z <= hi_z) & (b_hi_z >= lo_z);
+              if (__ballot(need) == 0ull) continue;
+              if (nb >= kMaxBlocks) {
+                too_big = true;  // more blocks than a byte slot can name
+                break;
+              }
+              if (lane == 0) blk[nb] = (int32_t)((uint32_t)(first_child + src) | ((uint32_t)tree << 31));
+              if (need) {
+                if (my_nblk < kMaxPerQuery) qblk[lane * kMaxPerQuery + my_nblk] = (uint8_t)nb;
+                my_nblk++;
+              }
+              nb++;
+            }
+          }
+        }
+      }
+      if (__ballot(my_nblk > kMaxPerQuery) != 0ull) too_big = true;  // a query needs more blocks than its list holds
+      if (too_big) {
+        // hand the packet's unfinished queries over to the lane kernel, from this level on
+        if (active) {
+          a.done[slot] = 0;
+          a.isect_sorted[slot] = isect;
+          a.next_level[slot] = level;
+          my_handed++;
+        }
+        wave_min_handover = min(wave_min_handover, level);
+        active = false;
+        break;
+      }
+      qrec[lane * kQrecStride + 11] = __int_as_float(my_nblk);  // read back by the teams
+
+      // ---- 4. passes ---------------------------------------------------------------------------
+      // The box grows 8x per level, so a query with a few others at the previous level will almost
+      // surely reach k now: such queries go straight to the fused count+select pass.  The rest are
+      // counted first and selected only if they turn out finished.  Either way the row is written
+      // only when the query really has >= k others, so speculation never changes a result.
+      qrec[lane * kQrecStride + 10] = __int_as_float(row);
+      qis[lane] = (uint64_t)isect;
+      const bool speculate = active && level > 0 && prev_others * 8u >= (uint32_t)(a.k + a.k / 2);
+      const bool count_first = active && !speculate;
+      {
+        const unsigned long long m = __ballot(count_first);
+        if (count_first) qlist[t_rank(m)] = lane;
+        t_wave_sync();
+        team_pass<false, HALO>(a, L, __popcll(m), level, own_pts, halo_pts, lane);
+        t_wave_sync();
+      }
+      uint32_t my_cnt = 0, my_oth = 0;
+      if (count_first) {
+        my_cnt = qcnt[lane * 2 + 0];
+        my_oth = qcnt[lane * 2 + 1];
+      }
+      const bool select_now = speculate || (count_first && my_oth >= (uint32_t)a.k);
+      {
+        const unsigned long long m = __ballot(select_now);
+        t_wave_sync();
+        if (select_now) qlist[t_rank(m)] = lane;
+        t_wave_sync();
+        team_pass<true, HALO>(a, L, __popcll(m), level, own_pts, halo_pts, lane);
+        t_wave_sync();
+      }
+      if (speculate) {
+        my_cnt = qcnt[lane * 2 + 0];
+        my_oth = qcnt[lane * 2 + 1];
+      }
+      if (active) {
+        isect += my_cnt;
+        my_levels++;
+        prev_others = my_oth;
+      }
+      const bool finished = active && my_oth >= (uint32_t)a.k;
+      {
+        // exact box tests executed for my query: LBVH_BLOCK per listed block and pass
+        const unsigned long long passes = (count_first ? 1ull : 0ull) + (select_now ? 1ull : 0ull);
+        wave_point_tests += t_wave_sum(active ? (unsigned long long)my_nblk * LBVH_BLOCK * passes : 0ull);
+      }
+      if (finished) my_isect_sum += (unsigned long long)isect;
+      active = active && !finished;
+      level++;
+      t_wave_sync();
+      if (__ballot(active) == 0ull) break;
+      if (level >= a.max_rounds) {
+        if (!a.allow_unfinished) wave_err |= 1;
+        break;
+      }
+      r = r * 2.0f;  // hostCode.cpp:321
+    }
+    wave_levels = max(wave_levels, level);
+    if (active) my_unfinished++;
+  }
+
+  const unsigned long long isum = t_wave_sum(my_isect_sum), lsum = t_wave_sum(my_levels), usum = t_wave_sum(my_unfinished), hsum = t_wave_sum(my_handed);
+  if (lane == 0) {
+    atomicMax(&a.counters[1], (unsigned long long)wave_levels);
+    atomicAdd(&a.counters[2], wave_node_tests);
+    atomicAdd(&a.counters[3], wave_point_tests);
+    atomicAdd(&a.counters[4], isum);
+    atomicAdd(&a.counters[6], lsum);
+    if (usum) atomicAdd(&a.counters[7], usum);
+    if (hsum) {
+      atomicAdd(&a.counters[8], hsum);
+      atomicMin(&a.counters[9], (unsigned long long)wave_min_handover);
+    }
+    if (wave_err) atomicOr(&a.counters[5], (unsigned long long)wave_err);
+  }
+}
+
+}  // namespace
+
+bool Engine::team_kernel_supports(int k) { return k >= 1 && k <= 16; }
+
+bool Engine::solve_team(const SolveArgs &sa, tknnSolveInfo *info, hipStream_t s) {
+  const int64_t n = bvh_.size();
+  TeamArgs a;
+  a.bvh = bvh_.view();
+  a.halo = halo_view();
+  a.wide[0] = bvh_.wide_view();
+  if (halo_n_ > 0)
+    a.wide[1] = halo_.wide_view();
+  else
+    std::memset(&a.wide[1], 0, sizeof(a.wide[1]));
+  a.start_radius = sa.start_radius;
+  a.k = sa.k;
+  a.max_rounds = sa.max_rounds;
+  a.allow_unfinished = sa.allow_unfinished ? 1 : 0;
+  a.ngroups = (int32_t)((n + 63) / 64);
+  a.out_idx = sa.d_idx;
+  a.out_dist = sa.d_dist;
+  a.out_isect = sa.d_isect;
+  a.out_fb = sa.d_fb;
+  a.out_level = sa.d_levels;
+  a.done = done_;
+  a.isect_sorted = isect_sorted_;
+  a.next_level = next_level_;
+  a.counters = counters_;
+
+  hipDeviceProp_t prop;
+  OWLMI_HIP(hipGetDeviceProperties(&prop, device_));
+  int per_cu = 2;
+  const size_t lds = (size_t)kTeamBlock / 64 * kTeamLds;
+  const bool with_halo = halo_n_ > 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, with_halo ? team_kernel<true> : team_kernel<false>, kTeamBlock, lds) != hipSuccess) per_cu = 2;
+  per_cu = std::max(1, per_cu);
+  const int64_t want = (a.ngroups + kTeamBlock / 64 - 1) / (kTeamBlock / 64);
+  const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>(want, (int64_t)prop.multiProcessorCount * per_cu));
+
+  OWLMI_HIP(hipMemsetAsync(counters_, 0, 16 * sizeof(unsigned long long), s));
+  OWLMI_HIP(hipMemsetAsync(counters_ + 9, 0xff, sizeof(unsigned long long), s));  // min hand-over level
+  OWLMI_HIP(hipMemsetAsync(done_, 1, (size_t)n, s));
+  if (sa.d_levels) OWLMI_HIP(hipMemsetAsync(sa.d_levels, 0xff, (size_t)n * sizeof(int32_t), s));
+  OWLMI_HIP(hipEventRecord(ev_a_, s));
+  if (with_halo)
+    hipLaunchKernelGGL(team_kernel<true>, dim3(blocks), dim3(kTeamBlock), lds, s, a);
+  else
+    hipLaunchKernelGGL(team_kernel<false>, dim3(blocks), dim3(kTeamBlock), lds, s, a);
+  OWLMI_HIP(hipGetLastError());
+  OWLMI_HIP(hipEventRecord(ev_b_, s));
+  OWLMI_HIP(hipMemcpyAsync(h_counters_, counters_, 10 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+  OWLMI_HIP(hipStreamSynchronize(s));
+  float ms = 0;
+  OWLMI_HIP(hipEventElapsedTime(&ms, ev_a_, ev_b_));
+  if (h_counters_[5] & 1ull) throw RoundsExceeded{};
+  if (info) {
+    const int rounds = (int)h_counters_[1];
+    info->rounds = rounds;
+    float radius = sa.start_radius;
+    for (int t = 1; t < rounds; t++) radius *= 2;
+    info->final_radius = radius;
+    info->node_tests = (int64_t)h_counters_[2];
+    info->point_tests = (int64_t)h_counters_[3];
+    info->total_intersections = (int64_t)h_counters_[4];
+    info->total_active_rounds = (int64_t)h_counters_[6];
+    info->solve_ms = ms;
+    info->dominant_kernel_ms = ms;
+    info->dominant_kernel_launches = 1;
+    info->kernel_used = TKNN_KERNEL_TEAM;
+    info->list_capacity = 16;
+    info->unfinished = (int64_t)h_counters_[7];
+  }
+  const unsigned long long handed = h_counters_[8];
+  if (handed) {
+    // stragglers whose candidate lists outgrew the LDS lists: the lane kernel finishes them,
+    // round by round, from the level at which each was handed over
+    tknnSolveInfo tail;
+    std::memset(&tail, 0, sizeof tail);
+    continue_lane(sa, (int)h_counters_[9], &tail, s);
+    if (info) {
+      info->rounds = std::max(info->rounds, tail.rounds);
+      float radius = sa.start_radius;
+      for (int t = 1; t < info->rounds; t++) radius *= 2;
+      info->final_radius = radius;
+      info->node_tests += tail.node_tests;
+      info->point_tests += tail.point_tests;
+      info->total_intersections += tail.total_intersections;
+      info->total_active_rounds += tail.total_active_rounds;
+      info->solve_ms += tail.solve_ms;
+      info->unfinished += tail.unfinished;
+    }
+  }
+  return true;
+}
+
+}  // namespace owlmi
