@@ -141,6 +141,21 @@ TKNN_API int tknnBuildIds(tknnEngine e, const float *d_xyz, const int32_t *d_ids
 TKNN_API int tknnSetHalo(tknnEngine e, const float *d_xyz, const int32_t *d_ids, int64_t m, void *stream);
 TKNN_API int tknnSolveEx(tknnEngine e, const tknnSolveOptions *options, tknnSolveInfo *info, void *stream);
 
+/* ---- RT-DBSCAN over the same tree -------------------------------------
+ * The reference tree holds no RT-DBSCAN source (README.md:8-9 mentions the method only), so the
+ * semantics are this build's own spec (oracle/dbscan_oracle.c): N(p) = {q : dist <= eps} with p
+ * included and the TrueKNN fp32 distance arithmetic; core iff |N(p)| >= min_pts; clusters =
+ * components of core points, numbered by ascending smallest core index; a border point joins the
+ * lowest-numbered adjacent cluster; noise = -1 (sklearn.cluster.DBSCAN's labelling).
+ *   d_labels n int32 (required) | d_core n uint8 (may be NULL) | d_counts n int32 |N(p)| (may be
+ *   NULL; asking for it disables the early exit of the core test).  Call tknnBuild first. */
+typedef struct {
+  int32_t clusters;
+  float solve_ms;
+} tknnDbscanInfo;
+TKNN_API int tknnDbscan(tknnEngine e, float eps, int min_pts, int32_t *d_labels, uint8_t *d_core,
+                        int32_t *d_counts, tknnDbscanInfo *info, void *stream);
+
 /* Test / debug export of the tree to host memory (any pointer may be NULL):
  *   nodes      (n-1) x 8 dwords {lo[3], split, hi[3], other}   (include/owl/lbvh_device.h)
  *   rope_node  n-1, rope_leaf n, prim_id n (caller index of sorted slot)            */

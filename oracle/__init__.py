@@ -14,6 +14,7 @@ from .loader import (  # noqa: F401
     OracleError,
     bruteforce_knn,
     build,
+    dbscan,
     distance,
     num_threads,
     trueknn,

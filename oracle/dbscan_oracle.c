@@ -1,0 +1,187 @@
+/*
+ * dbscan_oracle.c -- CPU statement of the RT-DBSCAN result this repo's HIP path must produce.
+ *
+ * TEST INFRASTRUCTURE ONLY (see oracle/__init__.py).
+ *
+ * PARITY UNPINNED, and more than for TrueKNN: the reference tree holds NO RT-DBSCAN source at all
+ * (samples/s02-rtdbscan does not exist; README.md:8-9 only says the method "offloads distance
+ * computations in DBSCAN to the ray tracing cores and performs other clustering operations in
+ * shader cores").  So this file is a SPEC written for this build, not a restatement:
+ *
+ *   neighbourhood   N(p) = { q : dist(p, q) <= eps }, p itself included; dist is the fp32
+ *                   arithmetic of the TrueKNN intersection program (deviceCode.cu:110-113 as
+ *                   written): sqrtf((dx*dx + dy*dy) + dz*dz), every operation rounded
+ *   core point      |N(p)| >= minPts
+ *   cluster         connected component of core points under  dist <= eps
+ *   border point    non-core with a core point in N(p): joins the adjacent cluster with the
+ *                   smallest label
+ *   labels          clusters numbered 0,1,... by ascending smallest core index; noise = -1
+ *
+ * With these rules the labelling is unique and is exactly what sklearn.cluster.DBSCAN returns
+ * (it expands clusters in index order, so cluster ids follow the smallest core index and a border
+ * point is taken by the lowest-numbered cluster that reaches it), except that sklearn measures
+ * distances in float64: tests compare with sklearn only on inputs where no pair lies within a few
+ * ulps of eps.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+static inline float db_dist(const float *a, const float *b) {
+  float x = a[0] - b[0], y = a[1] - b[1], z = a[2] - b[2];
+  return sqrtf(((x * x) + (y * y)) + (z * z));
+}
+
+typedef struct {
+  double org[3], inv;
+  int dim[3];
+  int64_t *start;
+  int32_t *items;
+} db_grid;
+
+static inline int db_cell(const db_grid *g, int a, double v) {
+  double t = (v - g->org[a]) * g->inv;
+  if (!(t > 0)) return 0;
+  if (t >= g->dim[a]) return g->dim[a] - 1;
+  return (int)t;
+}
+
+static int db_grid_build(db_grid *g, const float *xyz, int64_t n, double cell) {
+  double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+  for (int64_t i = 0; i < n; i++)
+    for (int a = 0; a < 3; a++) {
+      double v = xyz[3 * i + a];
+      if (v < lo[a]) lo[a] = v;
+      if (v > hi[a]) hi[a] = v;
+    }
+  for (;;) {
+    double tot = 1;
+    for (int a = 0; a < 3; a++) tot *= floor((hi[a] - lo[a]) / cell) + 1;
+    if (tot <= 8.0 * (double)n + 64) break;
+    cell *= 1.26;
+  }
+  int64_t ncell = 1;
+  g->inv = 1.0 / cell;
+  for (int a = 0; a < 3; a++) {
+    g->org[a] = lo[a];
+    g->dim[a] = (int)(floor((hi[a] - lo[a]) / cell) + 1);
+    ncell *= g->dim[a];
+  }
+  g->start = (int64_t *)calloc((size_t)ncell + 1, sizeof(int64_t));
+  g->items = (int32_t *)malloc((size_t)(n ? n : 1) * sizeof(int32_t));
+  int64_t *fill = (int64_t *)malloc((size_t)ncell * sizeof(int64_t));
+  if (!g->start || !g->items || !fill) return -1;
+#define DB_CELL_OF(i) \
+  (((int64_t)db_cell(g, 2, xyz[3 * (i) + 2]) * g->dim[1] + db_cell(g, 1, xyz[3 * (i) + 1])) * g->dim[0] + db_cell(g, 0, xyz[3 * (i)]))
+  for (int64_t i = 0; i < n; i++) g->start[DB_CELL_OF(i) + 1]++;
+  for (int64_t c = 0; c < ncell; c++) g->start[c + 1] += g->start[c];
+  memcpy(fill, g->start, (size_t)ncell * sizeof(int64_t));
+  for (int64_t i = 0; i < n; i++) g->items[fill[DB_CELL_OF(i)]++] = (int32_t)i;
+  free(fill);
+  return 0;
+}
+
+/* calls f(p, ctx) for every p with dist(p, q) <= eps (q itself included); returns count */
+typedef void (*db_visit)(int32_t p, void *ctx);
+static int64_t db_neighbours(const db_grid *g, const float *xyz, int32_t q, float eps, db_visit f, void *ctx) {
+  const float *c = xyz + 3 * (int64_t)q;
+  double reach = (double)eps * 1.0001 + 1e-30;
+  int c0[3], c1[3];
+  for (int a = 0; a < 3; a++) {
+    double slack = reach + 1e-6 * fabs((double)c[a]);
+    c0[a] = db_cell(g, a, (double)c[a] - slack);
+    c1[a] = db_cell(g, a, (double)c[a] + slack);
+  }
+  int64_t m = 0;
+  for (int z = c0[2]; z <= c1[2]; z++)
+    for (int y = c0[1]; y <= c1[1]; y++)
+      for (int x = c0[0]; x <= c1[0]; x++) {
+        int64_t cell = ((int64_t)z * g->dim[1] + y) * g->dim[0] + x;
+        for (int64_t s = g->start[cell]; s < g->start[cell + 1]; s++) {
+          int32_t p = g->items[s];
+          if (db_dist(xyz + 3 * (int64_t)p, c) <= eps) {
+            m++;
+            if (f) f(p, ctx);
+          }
+        }
+      }
+  return m;
+}
+
+static int32_t db_find(int32_t *parent, int32_t x) {
+  while (parent[x] != x) {
+    parent[x] = parent[parent[x]];
+    x = parent[x];
+  }
+  return x;
+}
+
+typedef struct {
+  int32_t *parent;
+  const uint8_t *core;
+  int32_t self;
+  int32_t best;
+} db_ctx;
+
+static void db_union_visit(int32_t p, void *vctx) {
+  db_ctx *c = (db_ctx *)vctx;
+  if (!c->core[p] || p == c->self) return;
+  int32_t a = db_find(c->parent, c->self), b = db_find(c->parent, p);
+  if (a == b) return;
+  if (a < b)
+    c->parent[b] = a; /* the smaller index stays root: roots are the smallest core index */
+  else
+    c->parent[a] = b;
+}
+
+static void db_border_visit(int32_t p, void *vctx) {
+  db_ctx *c = (db_ctx *)vctx;
+  if (!c->core[p]) return;
+  int32_t r = db_find(c->parent, p);
+  if (c->best < 0 || r < c->best) c->best = r;
+}
+
+/* xyz: n x 3 fp32.  labels: n int32 out.  core: n uint8 out.  counts: n int32 out (|N(p)|, may be NULL).
+ * returns the number of clusters, or <0 on bad arguments / out of memory. */
+int dbref_dbscan(const float *xyz, int64_t n, float eps, int min_pts, int32_t *labels, uint8_t *core,
+                 int32_t *counts) {
+  if (!xyz || !labels || !core || n <= 0 || !(eps > 0) || min_pts < 1) return -1;
+  db_grid g;
+  if (db_grid_build(&g, xyz, n, (double)eps)) return -2;
+  int32_t *parent = (int32_t *)malloc((size_t)n * sizeof(int32_t));
+  if (!parent) return -2;
+  for (int64_t i = 0; i < n; i++) {
+    int64_t m = db_neighbours(&g, xyz, (int32_t)i, eps, NULL, NULL);
+    core[i] = m >= min_pts;
+    if (counts) counts[i] = (int32_t)m;
+    parent[i] = (int32_t)i;
+  }
+  db_ctx ctx;
+  ctx.parent = parent;
+  ctx.core = core;
+  for (int64_t i = 0; i < n; i++)
+    if (core[i]) {
+      ctx.self = (int32_t)i;
+      db_neighbours(&g, xyz, (int32_t)i, eps, db_union_visit, &ctx);
+    }
+  /* roots in ascending index order get labels 0,1,...; borders take the smallest adjacent root */
+  int32_t *rank = (int32_t *)malloc((size_t)n * sizeof(int32_t));
+  if (!rank) return -2;
+  int32_t nclusters = 0;
+  for (int64_t i = 0; i < n; i++) rank[i] = (core[i] && db_find(parent, (int32_t)i) == i) ? nclusters++ : -1;
+  for (int64_t i = 0; i < n; i++) {
+    if (core[i]) {
+      labels[i] = rank[db_find(parent, (int32_t)i)];
+    } else {
+      ctx.best = -1;
+      db_neighbours(&g, xyz, (int32_t)i, eps, db_border_visit, &ctx);
+      labels[i] = ctx.best < 0 ? -1 : rank[ctx.best];
+    }
+  }
+  free(rank);
+  free(parent);
+  free(g.start);
+  free(g.items);
+  return nclusters;
+}

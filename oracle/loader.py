@@ -28,7 +28,8 @@ class OracleError(RuntimeError):
 def build(force=False):
     """Compile the C restatement (gcc); building the checker is not using it."""
     src = os.path.join(_HERE, "trueknn_oracle.c")
-    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+    src2 = os.path.join(_HERE, "dbscan_oracle.c")
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < max(os.path.getmtime(src), os.path.getmtime(src2)):
         subprocess.check_call(["make", "-C", _HERE, "-s", "clean", "all"])
     return _SO
 
@@ -58,6 +59,9 @@ def _load():
             ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_void_p, ctypes.c_int64,
             ctypes.c_void_p, ctypes.c_void_p,
         ]
+        lib.dbref_dbscan.restype = ctypes.c_int
+        lib.dbref_dbscan.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_float, ctypes.c_int,
+                                     ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
         assert lib.tkref_sizeof_neigh() == NEIGH_DTYPE.itemsize
         _lib = lib
     return _lib
@@ -136,3 +140,18 @@ def bruteforce_knn(xyz, k, query_ids=None):
     if rc:
         raise OracleError("bruteforce failed: %d" % rc)
     return idx, dist
+
+
+def dbscan(xyz, eps, min_pts):
+    """The RT-DBSCAN spec of oracle/dbscan_oracle.c: dict(labels, core, counts, clusters)."""
+    lib = _load()
+    xyz = _points(xyz)
+    n = len(xyz)
+    labels = np.empty(n, np.int32)
+    core = np.empty(n, np.uint8)
+    counts = np.empty(n, np.int32)
+    rc = lib.dbref_dbscan(xyz.ctypes.data, n, ctypes.c_float(eps), int(min_pts), labels.ctypes.data,
+                          core.ctypes.data, counts.ctypes.data)
+    if rc < 0:
+        raise OracleError("dbscan oracle failed: %d" % rc)
+    return {"labels": labels, "core": core.astype(bool), "counts": counts, "clusters": rc}

@@ -56,6 +56,13 @@ class SolveOptions(ctypes.Structure):
     ]
 
 
+class DbscanInfo(ctypes.Structure):
+    _fields_ = [("clusters", ctypes.c_int32), ("solve_ms", ctypes.c_float)]
+
+    def as_dict(self):
+        return {name: getattr(self, name) for name, _ in self._fields_}
+
+
 class BuildInfo(ctypes.Structure):
     _fields_ = [("build_ms", ctypes.c_float), ("device_bytes", ctypes.c_int64), ("n", ctypes.c_int32)]
 
@@ -80,6 +87,8 @@ SIGNATURES = {
                                    ctypes.c_void_p]),
     "tknnSolveEx": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(SolveOptions), ctypes.POINTER(SolveInfo),
                                    ctypes.c_void_p]),
+    "tknnDbscan": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_float, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
+                                  ctypes.c_void_p, ctypes.POINTER(DbscanInfo), ctypes.c_void_p]),
     "tknnExportTree": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                                       ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     "tknnDebugThresholds": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64,

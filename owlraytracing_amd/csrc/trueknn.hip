@@ -452,6 +452,20 @@ int tknnSolveEx(tknnEngine e, const tknnSolveOptions *options, tknnSolveInfo *in
   });
 }
 
+int tknnDbscan(tknnEngine e, float eps, int min_pts, int32_t *d_labels, uint8_t *d_core, int32_t *d_counts,
+               tknnDbscanInfo *info, void *stream) {
+  if (!e || !d_labels) {
+    g_last_error = "tknnDbscan: engine or labels pointer is NULL";
+    return TKNN_E_ARG;
+  }
+  return guarded([&] {
+    if (!e->impl.built()) throw owlmi::ArgError{TKNN_E_STATE, "tknnDbscan: call tknnBuild first"};
+    if (!(eps > 0.f) || !std::isfinite(eps)) throw owlmi::ArgError{TKNN_E_ARG, "tknnDbscan: eps must be finite and > 0"};
+    if (min_pts < 1) throw owlmi::ArgError{TKNN_E_ARG, "tknnDbscan: min_pts must be >= 1"};
+    e->impl.dbscan(eps, min_pts, d_labels, d_core, d_counts, info, (hipStream_t)stream);
+  });
+}
+
 int tknnExportTree(tknnEngine e, void *nodes, int32_t *rope_node, int32_t *rope_leaf, int32_t *prim_id,
                    void *stream) {
   if (!e) {

@@ -46,6 +46,8 @@ class Engine {
   void set_halo(const float *d_xyz, const int32_t *d_ids, int64_t m, hipStream_t s);
   LbvhView halo_view() const;
   void solve(const SolveArgs &sa, int kernel, tknnSolveInfo *info, hipStream_t s);
+  void dbscan(float eps, int min_pts, int32_t *d_labels, uint8_t *d_core, int32_t *d_counts, tknnDbscanInfo *info,
+              hipStream_t s);  // dbscan.hip
   bool built() const { return bvh_.built(); }
   int64_t size() const { return bvh_.size(); }
   const Lbvh &tree() const { return bvh_; }

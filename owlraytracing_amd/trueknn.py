@@ -130,6 +130,24 @@ class TrueKNN:
         out["info"] = self.last_info
         return out
 
+    def dbscan(self, eps, min_pts, want_counts=False):
+        """RT-DBSCAN over the built tree: dict(labels int32 (n,), core bool (n,), [counts], info)."""
+        torch = self._torch
+        n = self.n
+        with torch.cuda.device(self.device):
+            labels = torch.empty((n,), dtype=torch.int32, device=self.device)
+            core = torch.empty((n,), dtype=torch.uint8, device=self.device)
+            counts = torch.empty((n,), dtype=torch.int32, device=self.device) if want_counts else None
+            info = _lib.DbscanInfo()
+            _lib.check(self._lib.tknnDbscan(self._h, ctypes.c_float(eps), int(min_pts), ctypes.c_void_p(labels.data_ptr()),
+                                            ctypes.c_void_p(core.data_ptr()),
+                                            None if counts is None else ctypes.c_void_p(counts.data_ptr()),
+                                            ctypes.byref(info), self._stream()))
+        out = {"labels": labels, "core": core.bool(), "info": info.as_dict()}
+        if counts is not None:
+            out["counts"] = counts
+        return out
+
     def export_tree(self):
         """Host copies of the LBVH for tests: nodes (n-1,8) uint32 view, ropes, prim ids."""
         torch = self._torch

@@ -1,0 +1,116 @@
+"""RT-DBSCAN: the spec of oracle/dbscan_oracle.c against sklearn, and
+the HIP path against both.  The reference has no source for this, so parity is unpinned; sklearn's
+labelling is the external anchor."""
+import numpy as np
+import pytest
+
+import oracle
+from owlraytracing_amd import datasets
+
+
+def _boundary_free(xyz, eps, rel=1e-6):
+    """True if no pair of points has a distance within rel*eps of eps (float64 check), i.e. fp32
+    and float64 distance arithmetic must agree on every neighbourhood."""
+    from scipy.spatial import cKDTree
+    t = cKDTree(xyz.astype(np.float64))
+    near = t.query_pairs(eps * (1 + rel), output_type="ndarray")
+    d = np.linalg.norm(xyz[near[:, 0]].astype(np.float64) - xyz[near[:, 1]].astype(np.float64), axis=1)
+    return not np.any(np.abs(d - eps) <= rel * eps)
+
+
+def _pick_eps(xyz, eps):
+    """nudge eps until no pair distance is within rounding of it (so sklearn's float64 agrees)"""
+    for j in range(40):
+        e = float(np.float32(eps * (1 + 1e-3 * j)))
+        if _boundary_free(xyz, e):
+            return e
+    return None
+
+
+def _cases():
+    yield "blobs3d", datasets.gaussian_mixture3d(4000, components=6, sigma=0.02, seed=3), 0.012, 5
+    yield "uniform_sparse", datasets.uniform3d(3000, seed=4), 0.03, 4
+    yield "planar_taxi", datasets.pad_to_3d(datasets.taxi_like2d(4000, components=12, seed=5)), 0.004, 6
+    yield "minpts1", datasets.uniform3d(800, seed=6), 0.05, 1
+    yield "all_noise", datasets.uniform3d(500, seed=7), 0.001, 3
+
+
+@pytest.mark.parametrize("name,xyz,eps,min_pts", list(_cases()), ids=[c[0] for c in _cases()])
+def test_spec_equals_sklearn_labelling(name, xyz, eps, min_pts):
+    from sklearn.cluster import DBSCAN
+    eps32 = _pick_eps(xyz, eps)
+    if eps32 is None:
+        pytest.skip("no eps near the requested one is free of boundary pairs")
+    ref = oracle.dbscan(xyz, eps32, min_pts)
+    sk = DBSCAN(eps=eps32, min_samples=min_pts, algorithm="brute").fit(xyz.astype(np.float64))
+    core = np.zeros(len(xyz), bool)
+    core[sk.core_sample_indices_] = True
+    assert np.array_equal(ref["core"], core)
+    assert np.array_equal(ref["labels"], sk.labels_)  # identical numbering, not just a permutation
+    assert ref["clusters"] == (sk.labels_.max() + 1 if (sk.labels_ >= 0).any() else 0)
+
+
+def test_spec_invariants():
+    xyz = datasets.gaussian_mixture3d(3000, components=5, sigma=0.03, seed=9)
+    r = oracle.dbscan(xyz, 0.02, 4)
+    lab, core = r["labels"], r["core"]
+    assert np.all(lab[core] >= 0), "core points are never noise"
+    # cluster ids follow the smallest core index of each cluster
+    firsts = [np.flatnonzero(core & (lab == c))[0] for c in range(r["clusters"])]
+    assert firsts == sorted(firsts)
+    assert np.all(r["counts"] >= 1)
+    assert np.array_equal(core, r["counts"] >= 4)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,xyz,eps,min_pts", list(_cases()), ids=[c[0] for c in _cases()])
+def test_hip_dbscan_equals_the_spec(name, xyz, eps, min_pts):
+    from owlraytracing_amd.trueknn import TrueKNN
+    eps32 = float(np.float32(eps))
+    ref = oracle.dbscan(xyz, eps32, min_pts)
+    eng = TrueKNN()
+    eng.build(xyz)
+    got = eng.dbscan(eps32, min_pts, want_counts=True)
+    assert np.array_equal(got["core"].cpu().numpy(), ref["core"])
+    assert np.array_equal(got["counts"].cpu().numpy(), ref["counts"])
+    assert np.array_equal(got["labels"].cpu().numpy(), ref["labels"])
+    assert got["info"]["clusters"] == ref["clusters"]
+    fast = eng.dbscan(eps32, min_pts)  # early exit of the core test must not change anything
+    assert np.array_equal(fast["labels"].cpu().numpy(), ref["labels"])
+    eng.close()
+
+
+@pytest.mark.gpu
+def test_hip_dbscan_larger_mixture_against_the_spec_and_sklearn():
+    from sklearn.cluster import DBSCAN
+    from owlraytracing_amd.trueknn import TrueKNN
+    xyz = datasets.gaussian_mixture3d(200_000, components=64, sigma=0.02, seed=1)  # BASELINE config 3, scaled down
+    eps, min_pts = float(np.float32(0.01)), 4
+    ref = oracle.dbscan(xyz, eps, min_pts)
+    eng = TrueKNN()
+    eng.build(xyz)
+    got = eng.dbscan(eps, min_pts)
+    lab = got["labels"].cpu().numpy()
+    assert np.array_equal(lab, ref["labels"])
+    assert np.array_equal(got["core"].cpu().numpy(), ref["core"])
+    sub = np.arange(0, len(xyz), 1)[:30000]
+    if _boundary_free(xyz[sub], eps):
+        sk = DBSCAN(eps=eps, min_samples=min_pts).fit(xyz[sub].astype(np.float64))
+        r2 = oracle.dbscan(xyz[sub], eps, min_pts)
+        assert np.array_equal(r2["labels"], sk.labels_)
+    eng.close()
+
+
+@pytest.mark.gpu
+def test_hip_dbscan_argument_errors():
+    from owlraytracing_amd import _lib
+    from owlraytracing_amd.trueknn import TrueKNN
+    eng = TrueKNN()
+    with pytest.raises(_lib.TknnError):
+        eng.n = 10
+        eng.dbscan(0.1, 3)
+    eng.build(datasets.uniform3d(100, seed=1))
+    for eps, m in ((0.0, 3), (float("nan"), 3), (0.1, 0)):
+        with pytest.raises(_lib.TknnError):
+            eng.dbscan(eps, m)
+    eng.close()
