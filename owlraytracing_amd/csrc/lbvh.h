@@ -47,6 +47,7 @@ class Lbvh {
 
   LbvhView view() const;
   LbvhWideView wide_view() const;  // point trees only
+  const float *scene_device() const { return scene_; }  // 6 floats: lo xyz, hi xyz of the built set
   int64_t size() const { return n_; }
   bool built() const { return built_; }
   bool has_points() const { return points_ != nullptr && point_mode_; }

@@ -210,6 +210,8 @@ void Engine::build(const float *d_xyz, const int32_t *d_ids, int64_t n, tknnBuil
     OWLMI_HIP(hipMalloc((void **)&next_level_, (size_t)n * sizeof(int32_t)));
     state_cap_ = n;
   }
+  OWLMI_HIP(hipMemcpyAsync(scene_, bvh_.scene_device(), 6 * sizeof(float), hipMemcpyDeviceToHost, s));
+  OWLMI_HIP(hipStreamSynchronize(s));
   OWLMI_HIP(hipEventSynchronize(ev_b_));
   if (info) {
     float ms = 0;
@@ -305,8 +307,14 @@ void Engine::lane_rounds(const SolveArgs &sa, int first_level, bool fresh, tknnS
 void Engine::solve(const SolveArgs &sa, int kernel, tknnSolveInfo *info, hipStream_t s) {
   if (kernel == TKNN_KERNEL_TEAM && !team_kernel_supports(sa.k))
     throw ArgError{TKNN_E_UNSUPPORTED, "the team kernel holds one neighbour per lane of a 16-lane team: k <= 16"};
-  if (kernel == TKNN_KERNEL_AUTO)
-    kernel = team_kernel_supports(sa.k) ? TKNN_KERNEL_TEAM : (wave_kernel_available() ? TKNN_KERNEL_WAVE : TKNN_KERNEL_LANE);
+  if (kernel == TKNN_KERNEL_AUTO) {
+    // team kernel for k <= 16 unless the start radius is so small for the average density that many
+    // radius levels are certain (the per-round lane kernel only touches unfinished queries then)
+    if (team_kernel_supports(sa.k))
+      kernel = first_step_estimate(sa) <= 2 ? TKNN_KERNEL_TEAM : TKNN_KERNEL_LANE;
+    else
+      kernel = wave_kernel_available() ? TKNN_KERNEL_WAVE : TKNN_KERNEL_LANE;
+  }
   if (kernel == TKNN_KERNEL_TEAM) {
     if (solve_team(sa, info, s)) return;
     kernel = TKNN_KERNEL_WAVE;  // candidate sets too large for the team kernel's block masks

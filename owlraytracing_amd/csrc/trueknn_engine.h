@@ -62,6 +62,8 @@ class Engine {
   // trueknn_team.hip; returns false if a packet needed more leaf blocks than the kernel can name
   bool solve_team(const SolveArgs &sa, tknnSolveInfo *info, hipStream_t s);
   static bool team_kernel_supports(int k);
+  int first_step_estimate(const SolveArgs &sa) const;
+  float scene_[6] = {0, 0, 0, 0, 0, 0};  // bounds of the built point set (host copy)
 
   int device_ = 0;
   Lbvh bvh_;

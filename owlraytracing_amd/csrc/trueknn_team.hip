@@ -24,29 +24,35 @@
 //      team: lane j stores neighbour j (coalesced 4*k bytes per array).
 // Results are bit-identical to the other kernels: same thresholds, same distance arithmetic, keys
 // ordered by (dist, index).
+#include "knn_thresholds.h"
 #include "trueknn_engine.h"
 
 #include <algorithm>
+#include <cmath>
 #include <cstring>
 
 namespace owlmi {
 
 namespace {
 
-constexpr int kTeamBlock = 256;     // 4 independent waves per workgroup
+constexpr int kTeamBlock = 64;      // one wave per workgroup: LDS, not the block shape, limits residency
 constexpr int kMaxBlocks = 256;     // leaf blocks one packet may need per level (slot fits a byte)
 constexpr int kMaxPerQuery = 96;    // leaf blocks one query may need per level
 constexpr int kTeamStack = 256;     // wide-pyramid stack entries per wave
-constexpr int kQrecStride = 12;     // floats per LDS query record
+constexpr int kQrecStride = 20;     // floats per LDS query record (layout below)
+constexpr int kMaxStep = 2;          // radius levels one gather may serve
 // LDS per wave: query records | block list | per-query block lists | counts | query list | stack
 constexpr int kLdsQrec = 64 * kQrecStride * 4;
 constexpr int kLdsBlk = kMaxBlocks * 4;
 constexpr int kLdsMask = 64 * kMaxPerQuery;  // per-query lists of block slots (bytes)
-constexpr int kLdsCnt = 64 * 2 * 4 + 64 * 8;  // {cnt, others} per query + isect before this level
+constexpr int kLdsCnt = 64 * 4 * 4 + 64 * 8;  // {cnt[3], self} per query + isect before the chosen level
 constexpr int kLdsList = 64 * 4;
 constexpr int kLdsStack = kTeamStack * 4;
 constexpr int kTeamLds = kLdsQrec + kLdsBlk + kLdsMask + kLdsCnt + kLdsList + kLdsStack;
 
+// LDS query record: [0..2] q, [3] id, [4..9] thresholds of the box the pass works in (outermost
+// level of the step for COUNT, the finishing level for SELECT), [10] row, [11] #blocks,
+// [12..17] thresholds of the inner level of a two-level step, [18] level reported with the row
 struct TeamArgs {
   LbvhView bvh, halo;
   LbvhWideView wide[2];
@@ -54,6 +60,7 @@ struct TeamArgs {
   int k;
   int max_rounds;
   int allow_unfinished;
+  int first_step;  // levels the first gather of every packet serves (density estimate, 1..kMaxStep)
   int32_t ngroups;
   int32_t *out_idx;
   float *out_dist;
@@ -113,82 +120,6 @@ __device__ __forceinline__ uint32_t t_team_shr1(uint32_t v, uint32_t fill) {
   return (uint32_t)__builtin_amdgcn_update_dpp((int)fill, (int)v, 0x111 /*row_shr:1*/, 0xf, 0xf, false);
 }
 
-// thresholds: shared with the wave kernel (exact equivalents of fl(c - r) <= q <= fl(c + r))
-__device__ __forceinline__ uint32_t tf_ord(float f) {
-  uint32_t b = __float_as_uint(f);
-  return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
-}
-__device__ __forceinline__ float tf_unord(uint32_t u) {
-  return __uint_as_float((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u);
-}
-#define T_ORD_NEG_INF 0x007fffffu
-#define T_ORD_POS_INF 0xff800000u
-template <typename P>
-__device__ __forceinline__ uint32_t t_first_true(P pred, float guess) {
-  uint32_t u = tf_ord(guess);
-  u = u < T_ORD_NEG_INF ? T_ORD_NEG_INF : (u > T_ORD_POS_INF ? T_ORD_POS_INF : u);
-  uint32_t lo, hi;
-  if (pred(tf_unord(u))) {
-    hi = u;
-    uint32_t step = 1;
-    for (;;) {
-      uint32_t room = hi - T_ORD_NEG_INF;
-      if (room == 0) return hi;
-      uint32_t s = step < room ? step : room;
-      uint32_t t = hi - s;
-      if (pred(tf_unord(t))) {
-        if (t == T_ORD_NEG_INF) return t;
-        hi = t;
-        step <<= 1;
-      } else {
-        lo = t;
-        break;
-      }
-    }
-  } else {
-    lo = u;
-    uint32_t step = 1;
-    for (;;) {
-      uint32_t room = T_ORD_POS_INF - lo;
-      if (room == 0) return T_ORD_POS_INF + 1u;
-      uint32_t s = step < room ? step : room;
-      uint32_t t = lo + s;
-      if (pred(tf_unord(t))) {
-        hi = t;
-        break;
-      }
-      lo = t;
-      step <<= 1;
-    }
-  }
-  while (hi - lo > 1u) {
-    uint32_t mid = lo + ((hi - lo) >> 1);
-    if (pred(tf_unord(mid)))
-      hi = mid;
-    else
-      lo = mid;
-  }
-  return hi;
-}
-__device__ __forceinline__ float t_thr_lo(float q, float r) {
-#pragma clang fp contract(off)
-  if (!(q == q)) return INFINITY;
-  uint32_t key = t_first_true([=](float c) { return q <= c + r; }, q - r);
-  return key > T_ORD_POS_INF ? INFINITY : tf_unord(key);
-}
-__device__ __forceinline__ float t_thr_hi(float q, float r) {
-#pragma clang fp contract(off)
-  if (!(q == q)) return -INFINITY;
-  uint32_t key = t_first_true([=](float c) { return !(c - r <= q); }, q + r);
-  if (key <= T_ORD_NEG_INF) return -INFINITY;
-  return tf_unord(key - 1u);
-}
-__device__ __forceinline__ float t_gate(float w) {
-#pragma clang fp contract(off)
-  float w2 = w * w;
-  return w2 * 1.00000048f;
-}
-
 // one leaf block = LBVH_BLOCK sorted points, 16 bytes each; lane tl of a team reads point tl.
 // The sorted arrays are padded with NaN sentinels to whole blocks (lbvh.hip), so no bounds test.
 template <bool HALO>
@@ -210,7 +141,7 @@ struct TeamLds {
 // (deviceCode.cu:74,103).  SELECT = true: also keep the k best (dist,index) keys, lane j of the
 // team holding the j-th, and write the row if the query turns out finished (>= k others).
 template <bool SELECT, bool HALO>
-__device__ __forceinline__ void team_pass(const TeamArgs &a, const TeamLds &L, int n_list, int level,
+__device__ __forceinline__ void team_pass(const TeamArgs &a, const TeamLds &L, int n_list, int level, int m,
                                           const LbvhPoint *own_pts, const LbvhPoint *halo_pts, int lane) {
   const int team = lane >> 4, tl = lane & 15;
   const float qnan = __uint_as_float(0x7fc00000u);
@@ -222,6 +153,9 @@ __device__ __forceinline__ void team_pass(const TeamArgs &a, const TeamLds &L, i
     const float t_qx = rec[0], t_qy = rec[1], t_qz = rec[2];
     const int32_t t_qid = __float_as_int(rec[3]);
     const float t_lx = rec[4], t_ly = rec[5], t_lz = rec[6], t_hx = rec[7], t_hy = rec[8], t_hz = rec[9];
+    // inner levels of a multi-level COUNT step (m = levels served by this gather, wave-uniform)
+    const float i0_lx = rec[12], i0_ly = rec[13], i0_lz = rec[14], i0_hx = rec[15], i0_hy = rec[16], i0_hz = rec[17];
+    uint32_t cnt_i0 = 0;
     const int my_n = on ? __float_as_int(rec[11]) : 0;  // leaf blocks of my team's query
     int steps = my_n;                                   // wave-uniform trip count: longest list of the 4 teams
     steps = max(steps, (int)__builtin_amdgcn_readlane(my_n, 16));
@@ -232,7 +166,7 @@ __device__ __forceinline__ void team_pass(const TeamArgs &a, const TeamLds &L, i
     // (clamped to the last one; teams without a query read block 0 of the own tree and ignore it)
     const uint8_t *mine = L.qblk + qi * kMaxPerQuery;
     const int last = my_n - 1;
-    static_assert(kMaxPerQuery == 96, "entry registers below are written out for 6 x 16 entries");
+    static_assert(kMaxPerQuery <= 96, "entry registers below are written out for 6 x 16 entries");
     int32_t e0 = 0, e1 = 0, e2 = 0, e3 = 0, e4 = 0, e5 = 0;  // named, not an array: must stay in VGPRs
     if (my_n > 0) {
       e0 = L.blk[mine[min(tl, last)]];
@@ -259,10 +193,20 @@ __device__ __forceinline__ void team_pass(const TeamArgs &a, const TeamLds &L, i
       const LbvhPoint pc = load_block_point<HALO>(own_pts, halo_pts, entry_at(it + 2));
       LbvhPoint p = pa;
       if (it >= my_n) p.x = qnan;  // past the end of my list (or no query): fails every comparison
-      const bool in = (t_lx <= p.x) && (p.x <= t_hx) && (t_ly <= p.y) && (p.y <= t_hy) && (t_lz <= p.z) && (p.z <= t_hz);
+      // lo <= p <= hi on all axes, as "largest signed excess <= 0": the sign of a fp32 difference is
+      // exact, NaN (sentinels, list overrun) propagates to a false compare, and the whole test is
+      // 6 subtractions + 2 max3 + 1 max + 1 compare instead of a chain of mask operations
+      const float ex_lo = fmaxf(fmaxf(t_lx - p.x, t_ly - p.y), t_lz - p.z);
+      const float ex_hi = fmaxf(fmaxf(p.x - t_hx, p.y - t_hy), p.z - t_hz);
+      const bool in = fmaxf(ex_lo, ex_hi) <= 0.f && p.x == p.x;
       const bool is_self = in && (p.id == t_qid);  // ids are unique and a query lies in its own box
       cnt += in ? 1u : 0u;
       self += is_self ? 1u : 0u;
+      if (!SELECT && m > 1) {
+        const float a_lo = fmaxf(fmaxf(i0_lx - p.x, i0_ly - p.y), i0_lz - p.z);
+        const float a_hi = fmaxf(fmaxf(p.x - i0_hx, p.y - i0_hy), p.z - i0_hz);
+        cnt_i0 += (fmaxf(a_lo, a_hi) <= 0.f && in) ? 1u : 0u;
+      }
       if (SELECT) {
         const float d2 = knn_dist2(p.x, p.y, p.z, t_qx, t_qy, t_qz);
         bool pend = in && !is_self && (d2 <= tau2);
@@ -294,7 +238,7 @@ __device__ __forceinline__ void team_pass(const TeamArgs &a, const TeamLds &L, i
           } while (pm);
           // gate from the k-th best of my team
           const float w = __uint_as_float(t_lane_read(best_d, (team << 4) + a.k - 1));
-          tau2 = t_gate(w);
+          tau2 = knn_gate_from_worst(w);
         }
       }
       pa = pb;
@@ -303,9 +247,17 @@ __device__ __forceinline__ void team_pass(const TeamArgs &a, const TeamLds &L, i
     cnt = t_team_sum(cnt);
     self = t_team_sum(self);
     const uint32_t others = cnt - self;
+    if (!SELECT && m > 1) cnt_i0 = t_team_sum(cnt_i0);
     if (on && tl == 0) {
-      L.qcnt[qi * 2 + 0] = cnt;
-      L.qcnt[qi * 2 + 1] = others;
+      // counts innermost level first; a one-level pass fills slot 0
+      uint32_t *out = L.qcnt + qi * 4;
+      if (SELECT || m == 1) {
+        out[0] = cnt;
+      } else {
+        out[0] = cnt_i0;
+        out[1] = cnt;
+      }
+      out[3] = self;
     }
     if (SELECT) {
       // finished at this level (deviceCode.cu:118: k insertions happened): lane j < k stores neighbour j
@@ -329,7 +281,7 @@ __device__ __forceinline__ void team_pass(const TeamArgs &a, const TeamLds &L, i
         }
         if (tl == 0) {
           if (a.out_isect) a.out_isect[out_row] = tot;
-          if (a.out_level) a.out_level[out_row] = level;
+          if (a.out_level) a.out_level[out_row] = SELECT ? __float_as_int(rec[18]) : level;
         }
       }
     }
@@ -340,14 +292,14 @@ template <bool HALO>
 __global__ void __launch_bounds__(kTeamBlock) team_kernel(TeamArgs a) {
   extern __shared__ __align__(16) unsigned char smem[];
   const int lane = threadIdx.x & 63;
-  const int wid = threadIdx.x >> 6;
+  const int wid = threadIdx.x >> 6;  // 0 with one wave per workgroup
   const int tl = lane & 15;
   unsigned char *base = smem + wid * kTeamLds;
   float *qrec = (float *)base;
   int32_t *blk = (int32_t *)(base + kLdsQrec);
   uint8_t *qblk = (uint8_t *)(base + kLdsQrec + kLdsBlk);  // [query][kMaxPerQuery] slots into blk[]
   uint32_t *qcnt = (uint32_t *)(base + kLdsQrec + kLdsBlk + kLdsMask);
-  uint64_t *qis = (uint64_t *)(base + kLdsQrec + kLdsBlk + kLdsMask + 64 * 2 * 4);
+  uint64_t *qis = (uint64_t *)(base + kLdsQrec + kLdsBlk + kLdsMask + 64 * 4 * 4);
   int32_t *qlist = (int32_t *)(base + kLdsQrec + kLdsBlk + kLdsMask + kLdsCnt);
   int32_t *stack = (int32_t *)(base + kLdsQrec + kLdsBlk + kLdsMask + kLdsCnt + kLdsList);
 
@@ -372,6 +324,7 @@ __global__ void __launch_bounds__(kTeamBlock) team_kernel(TeamArgs a) {
     int level = 0;
     int64_t isect = 0;
     uint32_t prev_others = 0;  // others in my box at the previous level
+    int step = a.first_step;   // levels the next gather serves
     TeamLds L;
     L.qrec = qrec;
     L.blk = blk;
@@ -382,19 +335,31 @@ __global__ void __launch_bounds__(kTeamBlock) team_kernel(TeamArgs a) {
 
     for (;;) {  // radius levels
       // ---- 1. thresholds, query records ----------------------------------------------------
+      // This step serves levels level .. level+m-1 with ONE gather at the outermost radius.
+      int m = step < 1 ? 1 : (step > kMaxStep ? kMaxStep : step);
+      if (level + m > a.max_rounds) m = a.max_rounds - level;
+      const float r_in0 = r;                        // radius of the inner level of a two-level step
+      float r_out = r;
+      for (int j = 1; j < m; j++) r_out = r_out * 2.0f;
       float lo_x = INFINITY, lo_y = INFINITY, lo_z = INFINITY, hi_x = -INFINITY, hi_y = -INFINITY, hi_z = -INFINITY;
-      if (active) {
-        lo_x = t_thr_lo(q.x, r);
-        lo_y = t_thr_lo(q.y, r);
-        lo_z = t_thr_lo(q.z, r);
-        hi_x = t_thr_hi(q.x, r);
-        hi_y = t_thr_hi(q.y, r);
-        hi_z = t_thr_hi(q.z, r);
-      }
-      const float g_lo_x = t_wave_min(lo_x), g_lo_y = t_wave_min(lo_y), g_lo_z = t_wave_min(lo_z);
-      const float g_hi_x = t_wave_max(hi_x), g_hi_y = t_wave_max(hi_y), g_hi_z = t_wave_max(hi_z);
       {
         float *rec = qrec + lane * kQrecStride;
+        if (active) {
+          lo_x = thr_lo(q.x, r_out);
+          lo_y = thr_lo(q.y, r_out);
+          lo_z = thr_lo(q.z, r_out);
+          hi_x = thr_hi(q.x, r_out);
+          hi_y = thr_hi(q.y, r_out);
+          hi_z = thr_hi(q.z, r_out);
+          if (m > 1) {
+            rec[12] = thr_lo(q.x, r_in0);
+            rec[13] = thr_lo(q.y, r_in0);
+            rec[14] = thr_lo(q.z, r_in0);
+            rec[15] = thr_hi(q.x, r_in0);
+            rec[16] = thr_hi(q.y, r_in0);
+            rec[17] = thr_hi(q.z, r_in0);
+          }
+        }
         rec[0] = q.x;
         rec[1] = q.y;
         rec[2] = q.z;
@@ -406,6 +371,8 @@ __global__ void __launch_bounds__(kTeamBlock) team_kernel(TeamArgs a) {
         rec[8] = hi_y;
         rec[9] = hi_z;
       }
+      const float g_lo_x = t_wave_min(lo_x), g_lo_y = t_wave_min(lo_y), g_lo_z = t_wave_min(lo_z);
+      const float g_hi_x = t_wave_max(hi_x), g_hi_y = t_wave_max(hi_y), g_hi_z = t_wave_max(hi_z);
 
       // ---- 2+3. gather the packet's block list and the per-query masks ----------------------
       int my_nblk = 0;  // lane = query: how many blocks of the packet's list I need
@@ -479,45 +446,75 @@ __global__ void __launch_bounds__(kTeamBlock) team_kernel(TeamArgs a) {
       qrec[lane * kQrecStride + 11] = __int_as_float(my_nblk);  // read back by the teams
 
       // ---- 4. passes ---------------------------------------------------------------------------
-      // The box grows 8x per level, so a query with a few others at the previous level will almost
-      // surely reach k now: such queries go straight to the fused count+select pass.  The rest are
-      // counted first and selected only if they turn out finished.  Either way the row is written
-      // only when the query really has >= k others, so speculation never changes a result.
+      // One-level step: the box grows 8x per level, so a query with a few others at the previous
+      // level will almost surely reach k now and goes straight to the fused count+select pass; the
+      // rest are counted first and selected only if they turn out finished.  Multi-level step:
+      // count all m nested boxes in one pass, pick the first level with >= k others, select there.
+      // A row is written only when its query really has >= k others in the chosen box, so neither
+      // speculation nor level grouping can change a result.
       qrec[lane * kQrecStride + 10] = __int_as_float(row);
       qis[lane] = (uint64_t)isect;
-      const bool speculate = active && level > 0 && prev_others * 8u >= (uint32_t)(a.k + a.k / 2);
+      const bool speculate = m == 1 && active && level > 0 && prev_others * 8u >= (uint32_t)(a.k + a.k / 2);
       const bool count_first = active && !speculate;
       {
-        const unsigned long long m = __ballot(count_first);
-        if (count_first) qlist[t_rank(m)] = lane;
+        const unsigned long long cm = __ballot(count_first);
+        if (count_first) qlist[t_rank(cm)] = lane;
         t_wave_sync();
-        team_pass<false, HALO>(a, L, __popcll(m), level, own_pts, halo_pts, lane);
+        team_pass<false, HALO>(a, L, __popcll(cm), level, m, own_pts, halo_pts, lane);
         t_wave_sync();
       }
-      uint32_t my_cnt = 0, my_oth = 0;
+      // first level of the step at which I have >= k others (deviceCode.cu:118), -1 if none
+      uint32_t c0 = 0, c1 = 0, c2 = 0, selfc = 0;
+      int fin_at = -1;
       if (count_first) {
-        my_cnt = qcnt[lane * 2 + 0];
-        my_oth = qcnt[lane * 2 + 1];
+        c0 = qcnt[lane * 4 + 0];
+        c1 = m > 1 ? qcnt[lane * 4 + 1] : 0u;
+        c2 = m > 2 ? qcnt[lane * 4 + 2] : 0u;
+        selfc = qcnt[lane * 4 + 3];
+        if (c0 - selfc >= (uint32_t)a.k)
+          fin_at = 0;
+        else if (m > 1 && c1 - selfc >= (uint32_t)a.k)
+          fin_at = 1;
+        else if (m > 2 && c2 - selfc >= (uint32_t)a.k)
+          fin_at = 2;
       }
-      const bool select_now = speculate || (count_first && my_oth >= (uint32_t)a.k);
+      const bool select_now = speculate || fin_at >= 0;
+      if (m > 1 && fin_at >= 0 && fin_at < m - 1) {
+        // finishing inside the step: the SELECT pass works in that inner box
+        float *rec = qrec + lane * kQrecStride;
+        const float *src = rec + 12 + 6 * fin_at;
+#pragma unroll
+        for (int j = 0; j < 6; j++) rec[4 + j] = src[j];
+      }
+      if (fin_at > 0) qis[lane] = (uint64_t)isect + c0 + (fin_at > 1 ? c1 : 0u);  // levels before the chosen one
+      if (select_now) qrec[lane * kQrecStride + 18] = __int_as_float(level + (fin_at > 0 ? fin_at : 0));  // level reported for the row
       {
-        const unsigned long long m = __ballot(select_now);
+        const unsigned long long sm = __ballot(select_now);
         t_wave_sync();
-        if (select_now) qlist[t_rank(m)] = lane;
+        if (select_now) qlist[t_rank(sm)] = lane;
         t_wave_sync();
-        team_pass<true, HALO>(a, L, __popcll(m), level, own_pts, halo_pts, lane);
+        team_pass<true, HALO>(a, L, __popcll(sm), level, 1, own_pts, halo_pts, lane);
         t_wave_sync();
       }
+      bool finished = fin_at >= 0;
+      uint32_t last_others = 0;
       if (speculate) {
-        my_cnt = qcnt[lane * 2 + 0];
-        my_oth = qcnt[lane * 2 + 1];
+        c0 = qcnt[lane * 4 + 0];
+        selfc = qcnt[lane * 4 + 3];
+        finished = c0 - selfc >= (uint32_t)a.k;
+        fin_at = finished ? 0 : -1;
       }
+      int levels_run = 0;
       if (active) {
-        isect += my_cnt;
-        my_levels++;
-        prev_others = my_oth;
+        levels_run = finished ? fin_at + 1 : m;
+        isect += c0;
+        if (levels_run > 1) isect += c1;
+        if (levels_run > 2) isect += c2;
+        my_levels += (unsigned long long)levels_run;
+        last_others = (m > 2 ? c2 : (m > 1 ? c1 : c0)) - selfc;
+        prev_others = last_others;
       }
-      const bool finished = active && my_oth >= (uint32_t)a.k;
+      wave_levels = max(wave_levels, (int)t_wave_max((float)(active ? level + levels_run : 0)));
       {
         // exact box tests executed for my query: LBVH_BLOCK per listed block and pass
         const unsigned long long passes = (count_first ? 1ull : 0ull) + (select_now ? 1ull : 0ull);
@@ -525,16 +522,26 @@ __global__ void __launch_bounds__(kTeamBlock) team_kernel(TeamArgs a) {
       }
       if (finished) my_isect_sum += (unsigned long long)isect;
       active = active && !finished;
-      level++;
+      level += m;
       t_wave_sync();
       if (__ballot(active) == 0ull) break;
       if (level >= a.max_rounds) {
         if (!a.allow_unfinished) wave_err |= 1;
         break;
       }
-      r = r * 2.0f;  // hostCode.cpp:321
+      for (int j = 0; j < m; j++) r = r * 2.0f;  // hostCode.cpp:321
+      // how many levels the next gather should serve: the box grows 8x per level; group levels as
+      // long as even the best-off unfinished query is unlikely to collect k others
+      {
+        const float pmax = t_wave_max(active ? (float)last_others : 0.f);
+        float expect = pmax * 8.f;
+        step = 1;
+        while (step < kMaxStep && expect < 0.5f * (float)a.k) {
+          step++;
+          expect *= 8.f;
+        }
+      }
     }
-    wave_levels = max(wave_levels, level);
     if (active) my_unfinished++;
   }
 
@@ -558,6 +565,29 @@ __global__ void __launch_bounds__(kTeamBlock) team_kernel(TeamArgs a) {
 
 bool Engine::team_kernel_supports(int k) { return k >= 1 && k <= 16; }
 
+// How many radius levels the first gather of every packet should serve: with the average density
+// of the scene, the first level at which a box is expected to hold about k/2 other points.  Only
+// a work estimate -- every level is still resolved exactly.
+int Engine::first_step_estimate(const SolveArgs &sa) const {
+  double measure = 1.0;
+  int dims = 0;
+  for (int a = 0; a < 3; a++) {
+    const double e = (double)scene_[3 + a] - (double)scene_[a];
+    if (e > 0) {
+      measure *= e;
+      dims++;
+    }
+  }
+  if (dims == 0 || !(measure > 0)) return 1;
+  const double density = (double)bvh_.size() / measure;
+  double side = 2.0 * (double)sa.start_radius;
+  for (int m = 1; m < 3; m++) {
+    if (density * std::pow(side, dims) >= 0.5 * sa.k) return m;
+    side *= 2.0;
+  }
+  return 3;
+}
+
 bool Engine::solve_team(const SolveArgs &sa, tknnSolveInfo *info, hipStream_t s) {
   const int64_t n = bvh_.size();
   TeamArgs a;
@@ -572,6 +602,7 @@ bool Engine::solve_team(const SolveArgs &sa, tknnSolveInfo *info, hipStream_t s)
   a.k = sa.k;
   a.max_rounds = sa.max_rounds;
   a.allow_unfinished = sa.allow_unfinished ? 1 : 0;
+  a.first_step = first_step_estimate(sa);
   a.ngroups = (int32_t)((n + 63) / 64);
   a.out_idx = sa.d_idx;
   a.out_dist = sa.d_dist;

@@ -22,6 +22,7 @@
 // 0) and write their row; the rest double the radius (hostCode.cpp:321) and go again.  Because a
 // finished row is the k smallest (dist, index) among the candidates of its final box, recomputing
 // the list from scratch at each level gives the same row as the reference's incremental insertion.
+#include "knn_thresholds.h"
 #include "trueknn_engine.h"
 
 #include <algorithm>
@@ -63,87 +64,6 @@ __device__ __forceinline__ void wave_lds_sync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// fp32 <-> uint32 keys that ascend with the float order (-inf .. -0, +0 .. +inf)
-__device__ __forceinline__ uint32_t f_ord(float f) {
-  uint32_t b = __float_as_uint(f);
-  return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
-}
-__device__ __forceinline__ float f_unord(uint32_t u) {
-  return __uint_as_float((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u);
-}
-#define OWLMI_ORD_NEG_INF 0x007fffffu /* f_ord(-inf) */
-#define OWLMI_ORD_POS_INF 0xff800000u /* f_ord(+inf) */
-
-// Smallest float c (as an ordered key) for which the monotone predicate P holds, searched from
-// `guess`: gallop away from the guess in doubling strides, then bisect.  P must be false at -inf
-// side / true at +inf side of some boundary; the result is clamped to [-inf, +inf].  The guess is
-// normally within a few ulps, but NOT near zero or across binades (q ~ r), where a linear ulp walk
-// would take millions of steps -- hence the search on the key line.
-template <typename P>
-__device__ __forceinline__ uint32_t first_true_key(P pred, float guess) {
-  uint32_t u = f_ord(guess);
-  u = u < OWLMI_ORD_NEG_INF ? OWLMI_ORD_NEG_INF : (u > OWLMI_ORD_POS_INF ? OWLMI_ORD_POS_INF : u);
-  uint32_t lo, hi;  // invariant at the end: pred(hi) true (or hi == +inf), pred(lo) false (or lo == -inf)
-  if (pred(f_unord(u))) {
-    hi = u;
-    uint32_t step = 1;
-    for (;;) {
-      uint32_t room = hi - OWLMI_ORD_NEG_INF;
-      if (room == 0) return hi;
-      uint32_t s = step < room ? step : room;
-      uint32_t t = hi - s;
-      if (t != OWLMI_ORD_NEG_INF && pred(f_unord(t))) {
-        hi = t;
-        step <<= 1;
-      } else if (t == OWLMI_ORD_NEG_INF && pred(f_unord(t))) {
-        return t;
-      } else {
-        lo = t;
-        break;
-      }
-    }
-  } else {
-    lo = u;
-    uint32_t step = 1;
-    for (;;) {
-      uint32_t room = OWLMI_ORD_POS_INF - lo;
-      if (room == 0) return OWLMI_ORD_POS_INF + 1u;  // nothing satisfies P, not even +inf
-      uint32_t s = step < room ? step : room;
-      uint32_t t = lo + s;
-      if (pred(f_unord(t))) {
-        hi = t;
-        break;
-      }
-      lo = t;
-      step <<= 1;
-    }
-  }
-  while (hi - lo > 1u) {
-    uint32_t mid = lo + ((hi - lo) >> 1);
-    if (pred(f_unord(mid)))
-      hi = mid;
-    else
-      lo = mid;
-  }
-  return hi;
-}
-
-// smallest c with q <= fl(c + r)      (q <= fl(c + r)  <=>  c >= thr_lo(q, r))
-__device__ __forceinline__ float thr_lo(float q, float r) {
-#pragma clang fp contract(off)
-  if (!(q == q)) return INFINITY;
-  uint32_t key = first_true_key([=](float c) { return q <= c + r; }, q - r);
-  return key > OWLMI_ORD_POS_INF ? INFINITY : f_unord(key);
-}
-// largest c with fl(c - r) <= q       (fl(c - r) <= q  <=>  c <= thr_hi(q, r))
-__device__ __forceinline__ float thr_hi(float q, float r) {
-#pragma clang fp contract(off)
-  if (!(q == q)) return -INFINITY;
-  uint32_t key = first_true_key([=](float c) { return !(c - r <= q); }, q + r);  // first c that fails
-  if (key <= OWLMI_ORD_NEG_INF) return -INFINITY;
-  return f_unord(key - 1u);
-}
-
 __device__ __forceinline__ float wave_min(float v) {
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) v = fminf(v, __shfl_xor(v, off));
@@ -175,13 +95,6 @@ struct LaneState {
   uint32_t others;  // ... excluding myself                              deviceCode.cu:103
 };
 
-// squared-distance gate: every d2 with sqrt_rn(d2) <= w must pass ("queue gate")
-__device__ __forceinline__ float gate_from_worst(float w) {
-#pragma clang fp contract(off)
-  float w2 = w * w;
-  return w2 * 1.00000048f;  // 1 + 2^-21: at least 4 ulps above fl(w*w)
-}
-
 template <int K>
 __device__ __forceinline__ void flush_queue(LaneState<K> &st, const uint64_t *queue, int lane) {
   for (int s = 0; s < kQueueDepth; s++) {
@@ -193,7 +106,7 @@ __device__ __forceinline__ void flush_queue(LaneState<K> &st, const uint64_t *qu
     }
   }
   st.qpos = 0;
-  st.tau2 = gate_from_worst(knn_key_dist(st.list.worst()));
+  st.tau2 = knn_gate_from_worst(knn_key_dist(st.list.worst()));
 }
 
 template <int K>

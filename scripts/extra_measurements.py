@@ -1,0 +1,82 @@
+#!/usr/bin/env python3
+"""Side measurements for DESIGN.md (not the contract bench): non-uniform TrueKNN inputs, RT-DBSCAN at
+BASELINE config 3 scale, and the unchanged reference sample through the OWL program model."""
+import json
+import os
+import subprocess
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+
+from owlraytracing_amd import datasets  # noqa: E402
+from owlraytracing_amd.trueknn import TrueKNN  # noqa: E402
+
+out = {}
+
+
+def timed_solve(name, pts, k, r0, kernels=(3, 2, 1)):
+    eng = TrueKNN()
+    b = eng.build(torch.from_numpy(pts).cuda())
+    res = {"n": len(pts), "k": k, "r0": r0, "build_ms": b["build_ms"]}
+    for kern in kernels:
+        best = None
+        for _ in range(2):
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            r = eng.solve(k, r0, kernel=kern)
+            torch.cuda.synchronize()
+            w = (time.perf_counter() - t) * 1e3
+            best = w if best is None else min(best, w)
+        res["kernel_%d" % kern] = {"wall_ms": best, "rounds": r["info"]["rounds"], "used": r["info"]["kernel_used"],
+                                   "isect_per_query": r["info"]["total_intersections"] / len(pts)}
+        print(name, kern, res["kernel_%d" % kern], flush=True)
+    eng.close()
+    out[name] = res
+
+
+def main():
+    which = sys.argv[1:] or ["gmm", "taxi", "dbscan", "sample"]
+    if "gmm" in which:
+        pts = datasets.gaussian_mixture3d(10_000_000, components=64, sigma=0.02, seed=1)
+        timed_solve("trueknn_gmm3d_10M_k10", pts, 10, 0.0005)
+    if "taxi" in which:
+        pts = datasets.pad_to_3d(datasets.taxi_like2d(10_000_000, components=256, seed=2))
+        timed_solve("trueknn_taxi2d_10M_k10", pts, 10, 0.0002)
+    if "dbscan" in which:
+        for n in (1_000_000, 10_000_000):
+            pts = datasets.gaussian_mixture3d(n, components=64, sigma=0.02, seed=1)
+            eng = TrueKNN()
+            eng.build(torch.from_numpy(pts).cuda())
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            r = eng.dbscan(float(np.float32(0.01)), 4)
+            torch.cuda.synchronize()
+            w = (time.perf_counter() - t) * 1e3
+            lab = r["labels"]
+            out["dbscan_gmm3d_%d_eps0.01_minpts4" % n] = {
+                "wall_ms": w, "device_ms": r["info"]["solve_ms"], "clusters": r["info"]["clusters"],
+                "noise": int((lab < 0).sum()), "core": int(r["core"].sum())}
+            print("dbscan", n, out["dbscan_gmm3d_%d_eps0.01_minpts4" % n], flush=True)
+            eng.close()
+    if "sample" in which:
+        exe = os.path.join(ROOT, "oracle", "_ref", "sample01-trueknn")
+        if os.path.exists(exe):
+            for n in (1_000_000,):
+                pts = datasets.uniform3d(n, seed=0)
+                csv = "/tmp/pts_%d.csv" % n
+                np.savetxt(csv, pts, fmt="%.9g", delimiter=",")
+                r0 = datasets.start_radius(n, 10)
+                p = subprocess.run([exe, csv, str(n), "3", repr(r0), "10", "/tmp/time.txt"], capture_output=True, text=True, timeout=900)
+                lines = [l for l in p.stdout.splitlines() if "time" in l.lower() or l.startswith("Round:")]
+                out["unchanged_reference_sample_n%d_k10" % n] = {"rc": p.returncode, "lines": lines[-8:]}
+                print("sample", n, lines[-8:], flush=True)
+    json.dump(out, open(os.path.join(ROOT, "gpurun_out", "extra_measurements.json"), "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main()
