@@ -77,6 +77,7 @@ def main():
     ap.add_argument("--k", type=int, default=K)
     ap.add_argument("--kernel", type=int, default=0, help="0 auto, 1 lane, 2 wave")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--sharded", action="store_true", help="use the Morton-tile / halo-exchange driver even for one rank")
     args = ap.parse_args()
 
     from owlraytracing_amd import _lib, datasets
@@ -92,12 +93,19 @@ def main():
     dev = torch.device("cuda", local_rank)
 
     n, k = args.n, args.k
-    if world > 1:
+    sharded = world > 1 or args.sharded
+    if sharded:
         import torch.distributed as dist
 
         from owlraytracing_amd import distributed as tkd
 
-        dist.init_process_group("nccl", device_id=dev)
+        if not dist.is_initialized():
+            if "RANK" not in os.environ:  # plain `python bench.py --sharded`: a one-rank group
+                os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+                os.environ.setdefault("MASTER_PORT", "29577")
+                os.environ.setdefault("RANK", "0")
+                os.environ.setdefault("WORLD_SIZE", "1")
+            dist.init_process_group("nccl", device_id=dev)
         n_total = n * world
         r0 = datasets.start_radius(n_total, k)
         solver = tkd.ShardedTrueKNN(dev, kernel=args.kernel)
@@ -143,7 +151,7 @@ def main():
     kern_ms = float(np.mean([i["dominant_kernel_ms"] for i in infos]))
     total_isect = int(info["total_intersections"])
     total_rounds_active = int(info["total_active_rounds"])
-    n_local = len(solver.points) if world > 1 else n
+    n_local = len(solver.points) if sharded else n
     alg_bytes = algorithmic_bytes(n_local, k, total_isect, total_rounds_active)
     launches = max(int(info["dominant_kernel_launches"]), 1)
     achieved = alg_bytes / launches / (kern_ms * 1e-3) / 1e9
@@ -176,12 +184,12 @@ def main():
         "config": {
             "workload": "TrueKNN on %d uniform-random 3-D points per GPU (numpy default_rng(0), [0,1)^3), k=%d, "
                         "start radius 0.25*(k/n)^(1/3)=%.6g; BASELINE.json configs[1]%s" % (
-                            n_local, k, r0, "" if world == 1 else "; %d Morton tiles, RCCL halo exchange" % world),
+                            n_local, k, r0, "" if not sharded else "; %d Morton tiles, RCCL halo exchange" % world),
             "n_points_total": n_total,
             "k": k,
             "start_radius": r0,
             "kernel": kernel_name,
-            "parallelism": "1 GPU" if world == 1 else "%d Morton tiles + halo exchange" % world,
+            "parallelism": "1 GPU" if not sharded else "%d Morton tiles + halo exchange" % world,
         },
         "rounds": int(info["rounds"]),
         "intersection_program_calls_per_s": total_isect * world / (ms_per_step * 1e-3) if world == 1 else None,
@@ -201,10 +209,10 @@ def main():
             "timing": "HIP events on the launch stream, recorded inside libowl_mi355x.so around the kernel",
         },
     }
-    if world == 1:
+    if not sharded:
         line["build_ms"] = float(build_info["build_ms"])
         line["tree_bytes"] = int(build_info["device_bytes"])
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and not sharded and not args.no_cpu_baseline:
         cb, ref, q = cpu_baseline(xyz_host, k, r0)
         line["cpu_baseline"] = cb
         # the sample doubles as a parity spot check of the benchmarked run itself

@@ -135,3 +135,19 @@ def test_counter_based_points_do_not_depend_on_sharding():
     a = datasets.uniform3d_counter(0, datasets.CHUNK - 5)
     b = datasets.uniform3d_counter(datasets.CHUNK - 5, 3 * datasets.CHUNK // 2)
     assert np.array_equal(np.concatenate([a, b]), whole)
+
+
+def test_start_radius_sampler_is_seeded_and_sane():
+    from owlraytracing_amd.radius import sample_start_radius
+    xyz = datasets.uniform3d(5000, seed=12)
+    r = sample_start_radius(xyz, n_samples=100, seed=3)
+    assert r == sample_start_radius(xyz, n_samples=100, seed=3)
+    assert 0 < r < 0.5
+    # it is the smallest pairwise distance inside the sample
+    pick = np.random.default_rng(3).choice(5000, 100, replace=False)
+    s = xyz[pick].astype(np.float64)
+    d = np.sqrt(((s[:, None] - s[None]) ** 2).sum(-1))
+    d[np.arange(100), np.arange(100)] = np.inf
+    assert abs(r - d.min()) < 1e-12
+    # a solve started there terminates in a handful of rounds on uniform data
+    assert oracle.trueknn(xyz, 5, r)["rounds"] <= 8
