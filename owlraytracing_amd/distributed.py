@@ -6,9 +6,11 @@ path shards naturally -- queries are independent -- with ONE real exchange step:
 
   * the global point set is cut into W contiguous ranges of the 63-bit Morton order with equal
     counts (splitters from a sorted sample); rank g owns the queries and result rows of tile g and
-    keeps an LBVH over its own points (built once, like the single-GPU build);
+    keeps an LBVH over its own points (built once, like the single-GPU build); because a Morton
+    range is not spatially compact (Z-curve jumps), a tile is described by the bounding boxes of its
+    level-2 Morton cells (<= 64 compact boxes), not by one box;
   * per solve, every rank sends each peer the points of its tile that lie within the halo radius of
-    the peer's tile bounding box -- exactly the foreign points that can be box candidates of the
+    one of the peer's cell boxes -- exactly the foreign points that can be box candidates of the
     peer's queries (the reference's candidate test is an L-inf box) -- as one
     point-to-point exchange (RCCL send/recv over xGMI; a few MB per pair, latency-bound);
   * the engine searches own tree + halo tree; a query's row is exact as soon as its final radius
@@ -107,7 +109,9 @@ class ShardedTrueKNN:
         self.halo_levels = halo_levels  # first halo radius = start_radius * 2**halo_levels
         self.points = None      # (m,3) float32 owned points, on self.device
         self.ids = None         # (m,) int32 global ids of the owned points
-        self.tile_boxes = None  # (W,6) float64: lo xyz, hi xyz of every rank's tile
+        self.tile_boxes = None  # (W, MAX_CELLS, 6) float64 on the host: boxes of every rank's Morton cells
+        self.cell_boxes = None  # (C,6) my own cells
+        self.cell_slices = None  # [(start, end)] of my cells in self.points
         self.n_total = 0
         self.last = None
 
@@ -148,31 +152,77 @@ class ShardedTrueKNN:
         rows = torch.cat([points, ids.view(torch.float32).unsqueeze(1)], dim=1)  # 16-byte rows: x y z id-bits
         blocks = [rows[dest == p] for p in range(comm.world)]
         got = torch.cat(comm.exchange_rows(blocks, 4, torch.float32, dev), dim=0)
+        if len(got) == 0:
+            raise RuntimeError("rank %d received an empty tile; use fewer ranks for this point set" % comm.rank)
+        # keep the tile in Morton order: its cells are then contiguous slices
+        mycodes = morton63(got[:, :3], lo, extent)
+        order = torch.argsort(mycodes)
+        got, mycodes = got[order].contiguous(), mycodes[order]
         self.points = got[:, :3].contiguous()
         self.ids = got[:, 3].contiguous().view(torch.int32)
+        self._rows = got  # 16-byte wire rows: x y z id-bits
         n_local = torch.tensor([len(self.points)], dtype=torch.int64, device=dev)
         self.n_total = int(comm.all_reduce(n_local.clone(), dist.ReduceOp.SUM).item())
-        if len(self.points) == 0:
-            raise RuntimeError("rank %d received an empty tile; use fewer ranks for this point set" % comm.rank)
-        box = torch.cat([self.points.min(0).values, self.points.max(0).values]).double()
-        self.tile_boxes = comm.all_gather(box)
+        # A Morton range is NOT spatially compact: a tile that ends just past a jump of the Z curve
+        # has a bounding box spanning far-apart regions, and "points near the tile's box" would be
+        # most of the data set.  So a tile is described by the boxes of its level-2 Morton cells
+        # (<= 64 per tile, each inside one cell of the 4x4x4 grid, hence compact).
+        cells = mycodes >> (63 - 3 * self.CELL_LEVEL)
+        uniq, counts = torch.unique_consecutive(cells, return_counts=True)
+        ends = torch.cumsum(counts, 0).tolist()
+        starts = [0] + ends[:-1]
+        self.cell_slices = list(zip(starts, ends))
+        boxes = torch.full((self.MAX_CELLS, 6), float("inf"), dtype=torch.float64, device=dev)
+        boxes[:, 3:] = -float("inf")
+        for j, (s0, s1) in enumerate(self.cell_slices):
+            seg = self.points[s0:s1]
+            boxes[j, :3] = seg.min(0).values.double()
+            boxes[j, 3:] = seg.max(0).values.double()
+        self.cell_boxes = boxes[: len(self.cell_slices)].cpu()
+        self.tile_boxes = comm.all_gather(boxes).cpu()  # (W, MAX_CELLS, 6); empty slots are inverted boxes
         self.engine.build(self.points, self.ids)
+
+    CELL_LEVEL = 2
+    MAX_CELLS = 64
 
     # ---- per-solve exchange ---------------------------------------------------------------------
     def _halo_blocks(self, radius):
-        """rows of my tile within `radius` (L-inf, with rounding slack) of each peer's tile box"""
-        reach = float(radius) * (1.0 + 1e-5) + 1e-30
-        p64 = self.points.double()
-        rows = torch.cat([self.points, self.ids.view(torch.float32).unsqueeze(1)], dim=1)
+        """For each peer, the rows of my tile within `radius` (L-inf) of any of the peer's cell boxes:
+        exactly the foreign points that can be box candidates of the peer's queries.
+
+        Per peer: my cells whose box meets one of the peer's widened boxes are found on the host
+        (<= 64 x 64 tiny tests); only those slices are tested point by point, in float32 against
+        boxes widened in float64 (radius, a relative 1e-5, an ulp-of-coordinate margin) and rounded
+        OUTWARD, so the selection can only err on the side of sending a point too many."""
+        comm, dev = self.comm, self.device
+        rows = self._rows
         blocks = []
-        for p in range(self.comm.world):
-            if p == self.comm.rank:
+        reach = float(radius) * (1.0 + 1e-5) + 1e-30
+        mine = self.cell_boxes  # (C,6) float64, host
+        for peer in range(comm.world):
+            if peer == comm.rank:
                 blocks.append(rows[:0])
                 continue
-            lo, hi = self.tile_boxes[p, :3] - reach, self.tile_boxes[p, 3:] + reach
-            slack = 1e-6 * p64.abs()  # fl(c +- r) may move a box face by an ulp of the coordinate
-            mask = ((p64 + slack >= lo) & (p64 - slack <= hi)).all(dim=1)
-            blocks.append(rows[mask])
+            pb = self.tile_boxes[peer]
+            pb = pb[pb[:, 0] <= pb[:, 3]]  # drop empty slots
+            mag = pb.abs().max(dim=1, keepdim=True).values
+            lo64, hi64 = pb[:, :3] - reach - 1e-6 * mag, pb[:, 3:] + reach + 1e-6 * mag
+            # which of my cells meet any widened peer box (host)
+            meet = ((mine[:, None, :3] <= hi64[None]) & (mine[:, None, 3:] >= lo64[None])).all(dim=2)  # (C,P)
+            lo = lo64.float()
+            hi = hi64.float()
+            lo = torch.where(lo.double() > lo64, torch.nextafter(lo, torch.full_like(lo, -float("inf"))), lo).to(dev)
+            hi = torch.where(hi.double() < hi64, torch.nextafter(hi, torch.full_like(hi, float("inf"))), hi).to(dev)
+            picked = []
+            for c, (s0, s1) in enumerate(self.cell_slices):
+                which = torch.nonzero(meet[c]).flatten()
+                if len(which) == 0:
+                    continue
+                seg = self.points[s0:s1]
+                blo, bhi = lo[which.to(dev)], hi[which.to(dev)]
+                inside = ((seg[:, None, :] >= blo[None]) & (seg[:, None, :] <= bhi[None])).all(dim=2).any(dim=1)
+                picked.append(rows[s0:s1][inside])
+            blocks.append(torch.cat(picked, dim=0) if picked else rows[:0])
         return blocks
 
     def solve(self, k, start_radius, max_rounds=64, want_fb=False):

@@ -74,7 +74,16 @@ def main():
     solver = tkd.ShardedTrueKNN(dev, engine_factory=None if use_gpu else CheckerEngine, halo_levels=int(os.environ.get("HALO_LEVELS", "1")))
     solver.load_points(torch.from_numpy(pts[lo:hi]), torch.arange(lo, hi, dtype=torch.int32))
     r0 = float(os.environ.get("START_RADIUS", datasets.start_radius(n, k)))
+    import time
+    t0 = time.perf_counter()
     info = solver.solve(k, r0)
+    if use_gpu:
+        torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    info = solver.solve(k, r0)
+    if use_gpu:
+        torch.cuda.synchronize()
+    print('rank %d tile=%d halo=%d exchanges=%d solve_s first=%.4f second=%.4f kernel_ms=%.2f' % (rank, len(solver.points), info['halo_points'], info['halo_exchanges'], t1 - t0, time.perf_counter() - t1, info['dominant_kernel_ms']), flush=True)
     gids, idx, dst, isect = solver.gather_rows()
     if rank == 0:
         np.savez(out, gids=gids, idx=idx, dist=dst, isect=isect, rounds=info["rounds"],

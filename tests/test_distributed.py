@@ -22,6 +22,7 @@ def _run(engine, world, n, k, name, tmp_path, port, env_extra=None, timeout=600)
            "--master-addr", "127.0.0.1", "--master-port", str(port), WORKER, engine, str(n), str(k), name, out]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env, cwd=ROOT)
     assert r.returncode == 0, (r.stdout[-3000:] + r.stderr[-3000:])
+    print("\n".join(l for l in r.stdout.splitlines() if l.startswith("rank ")))
     return np.load(out)
 
 
@@ -58,3 +59,13 @@ def test_two_ranks_sharing_one_gpu_with_the_hip_engine(tmp_path):
     n, k = 200_000, 10
     got = _run("hip", 2, n, k, "uniform", tmp_path, 29641, {"HALO_LEVELS": "2"})
     _check(got, "uniform", n, k)
+
+
+@pytest.mark.gpu
+def test_four_ranks_sharing_one_gpu_cross_z_curve_jumps(tmp_path):
+    """4 Morton tiles: two of the three tile boundaries sit at jumps of the Z curve; the per-cell
+    tile boxes keep the halo small there (a single bounding box per tile would pull in whole tiles)."""
+    n, k = 400_000, 10
+    got = _run("hip", 4, n, k, "uniform", tmp_path, 29651, {"HALO_LEVELS": "2"})
+    _check(got, "uniform", n, k)
+    assert int(got["halo_points"]) < int(got["tile"]) // 2
