@@ -141,6 +141,17 @@ TKNN_API int tknnBuildIds(tknnEngine e, const float *d_xyz, const int32_t *d_ids
 TKNN_API int tknnSetHalo(tknnEngine e, const float *d_xyz, const int32_t *d_ids, int64_t m, void *stream);
 TKNN_API int tknnSolveEx(tknnEngine e, const tknnSolveOptions *options, tknnSolveInfo *info, void *stream);
 
+/* ---- exact kNN on request ---------------------------------------------------
+ * tknnSolve reproduces the reference, whose rows are box-candidate kNN, not exact kNN: a query
+ * that finished with box half-width r_q never saw points outside that box, although its k-th
+ * distance d_k may exceed r_q (15-20 % of rows on uniform data).  tknnRepairExact rewrites exactly
+ * those rows (d_k > r_q) with the true k nearest neighbours, same (dist, index) order, by one more
+ * traversal with radius d_k.  Opt-in post-processing: it is never applied by tknnSolve, so parity
+ * with the reference is unaffected.  Inputs: the rows and d_levels of a tknnSolveEx call and the
+ * start radius it used; intersections / frameBuffer images are not touched. */
+TKNN_API int tknnRepairExact(tknnEngine e, int k, float start_radius, const int32_t *d_levels,
+                             int32_t *d_idx, float *d_dist, int64_t *repaired, void *stream);
+
 /* ---- RT-DBSCAN over the same tree -------------------------------------
  * The reference tree holds no RT-DBSCAN source (README.md:8-9 mentions the method only), so the
  * semantics are this build's own spec (oracle/dbscan_oracle.c): N(p) = {q : dist <= eps} with p

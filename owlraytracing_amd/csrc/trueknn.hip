@@ -146,6 +146,72 @@ void launch_lane(const LaneRoundArgs &a, hipStream_t s) {
   hipLaunchKernelGGL(lane_round_kernel<K>, dim3(blocks), dim3(kLaneBlock), 0, s, a);
 }
 
+// ---- exact-kNN repair (opt-in, never part of tknnSolve) ----------------
+// The reference's rows are box-candidate kNN: a query that finished with radius r_q only ever saw
+// points inside its L-inf box, so when its k-th distance d_k exceeds r_q a closer point may sit
+// outside the box (15-20 % of rows on uniform data).  Every true neighbour has
+// Euclidean distance <= d_k, hence lies in the box of half-width d_k: one more traversal with
+// that radius, same (dist, index) order, gives the exact row.
+struct RepairArgs {
+  LbvhView bvh, halo;
+  int k;
+  float start_radius;
+  const int32_t *levels;  // per caller row: level at which the query finished
+  int32_t *idx;           // n*k rows, read (d_k) and rewritten
+  float *dist;
+  unsigned long long *counters;  // [0] rows repaired
+};
+
+template <int K>
+__global__ void __launch_bounds__(kLaneBlock) repair_kernel(RepairArgs a) {
+  const int32_t t = blockIdx.x * kLaneBlock + threadIdx.x;
+  if (t >= a.bvh.n) return;
+  const LbvhPoint q = a.bvh.points[t];
+  const int32_t row = a.bvh.prim_id[t];
+  const int32_t level = a.levels[row];
+  if (level < 0) return;
+  float rq = a.start_radius;
+  for (int i = 0; i < level; i++) rq *= 2;
+  const float dk = a.dist[(int64_t)row * a.k + a.k - 1];
+  if (!(dk > rq)) return;  // the ball of radius d_k is inside the box already searched
+  const float r = dk * 1.000001f;  // the rounded box test must not cut a point at distance d_k
+  KList<K> list;
+  list.clear();
+  for (int tree = 0; tree < 2; tree++) {
+    const LbvhView &tv = tree == 0 ? a.bvh : a.halo;
+    if (tv.n <= 0) continue;
+    int32_t ref = tv.root;
+    while (ref != LBVH_END) {
+      if (ref >= 0) {
+        const LbvhNode nd = tv.nodes[ref];
+        const bool hit = (nd.lo[0] - r <= q.x) & (q.x <= nd.hi[0] + r) & (nd.lo[1] - r <= q.y) &
+                         (q.y <= nd.hi[1] + r) & (nd.lo[2] - r <= q.z) & (q.z <= nd.hi[2] + r);
+        ref = hit ? lbvh_left_ref(ref, nd) : tv.rope_node[ref];
+      } else {
+        const int32_t slot = ~ref;
+        const LbvhPoint p = tv.points[slot];
+        if (p.id != q.id && knn_in_box(p.x, p.y, p.z, r, q.x, q.y, q.z))
+          list.insert(knn_key(knn_sqrt(knn_dist2(p.x, p.y, p.z, q.x, q.y, q.z)), p.id));
+        ref = tv.rope_leaf[slot];
+      }
+    }
+  }
+  const int64_t base = (int64_t)row * a.k;
+#pragma unroll
+  for (int j = 0; j < K; j++)
+    if (j < a.k) {
+      a.idx[base + j] = knn_key_prim(list.key[j]);
+      a.dist[base + j] = knn_key_dist(list.key[j]);
+    }
+  atomicAdd(&a.counters[0], 1ull);
+}
+
+template <int K>
+void launch_repair(const RepairArgs &a, hipStream_t s) {
+  unsigned blocks = (unsigned)((a.bvh.n + kLaneBlock - 1) / kLaneBlock);
+  hipLaunchKernelGGL(repair_kernel<K>, dim3(blocks), dim3(kLaneBlock), 0, s, a);
+}
+
 }  // namespace
 
 int list_capacity_for(int k) {
@@ -304,6 +370,36 @@ void Engine::lane_rounds(const SolveArgs &sa, int first_level, bool fresh, tknnS
   }
 }
 
+int64_t Engine::repair_exact(int k, float start_radius, const int32_t *d_levels, int32_t *d_idx, float *d_dist,
+                             hipStream_t s) {
+  RepairArgs a;
+  a.bvh = bvh_.view();
+  a.halo = halo_view();
+  a.k = k;
+  a.start_radius = start_radius;
+  a.levels = d_levels;
+  a.idx = d_idx;
+  a.dist = d_dist;
+  a.counters = counters_;
+  OWLMI_HIP(hipMemsetAsync(counters_, 0, sizeof(unsigned long long), s));
+  switch (list_capacity_for(k)) {
+    case 1: launch_repair<1>(a, s); break;
+    case 2: launch_repair<2>(a, s); break;
+    case 4: launch_repair<4>(a, s); break;
+    case 5: launch_repair<5>(a, s); break;
+    case 8: launch_repair<8>(a, s); break;
+    case 10: launch_repair<10>(a, s); break;
+    case 16: launch_repair<16>(a, s); break;
+    case 24: launch_repair<24>(a, s); break;
+    case 32: launch_repair<32>(a, s); break;
+    default: launch_repair<64>(a, s); break;
+  }
+  OWLMI_HIP(hipGetLastError());
+  OWLMI_HIP(hipMemcpyAsync(h_counters_, counters_, sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+  OWLMI_HIP(hipStreamSynchronize(s));
+  return (int64_t)h_counters_[0];
+}
+
 void Engine::solve(const SolveArgs &sa, int kernel, tknnSolveInfo *info, hipStream_t s) {
   if (kernel == TKNN_KERNEL_TEAM && !team_kernel_supports(sa.k))
     throw ArgError{TKNN_E_UNSUPPORTED, "the team kernel holds one neighbour per lane of a 16-lane team: k <= 16"};
@@ -457,6 +553,22 @@ int tknnSolveEx(tknnEngine e, const tknnSolveOptions *options, tknnSolveInfo *in
     sa.allow_unfinished = options->allow_unfinished != 0;
     if (info) std::memset(info, 0, sizeof(*info));
     e->impl.solve(sa, kernel, info, (hipStream_t)stream);
+  });
+}
+
+int tknnRepairExact(tknnEngine e, int k, float start_radius, const int32_t *d_levels, int32_t *d_idx,
+                    float *d_dist, int64_t *repaired, void *stream) {
+  if (!e || !d_levels || !d_idx || !d_dist) {
+    g_last_error = "tknnRepairExact: engine, levels, idx and dist are required";
+    return TKNN_E_ARG;
+  }
+  return guarded([&] {
+    if (!e->impl.built()) throw owlmi::ArgError{TKNN_E_STATE, "tknnRepairExact: call tknnBuild first"};
+    if (k <= 0 || k > TKNN_MAX_K) throw owlmi::ArgError{TKNN_E_ARG, "tknnRepairExact: k out of range"};
+    if (!(start_radius > 0.f) || !std::isfinite(start_radius))
+      throw owlmi::ArgError{TKNN_E_ARG, "tknnRepairExact: start_radius must be the one the rows were solved with"};
+    const int64_t n = e->impl.repair_exact(k, start_radius, d_levels, d_idx, d_dist, (hipStream_t)stream);
+    if (repaired) *repaired = n;
   });
 }
 

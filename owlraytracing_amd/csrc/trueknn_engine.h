@@ -46,6 +46,8 @@ class Engine {
   void set_halo(const float *d_xyz, const int32_t *d_ids, int64_t m, hipStream_t s);
   LbvhView halo_view() const;
   void solve(const SolveArgs &sa, int kernel, tknnSolveInfo *info, hipStream_t s);
+  // rewrites the rows whose k-th distance exceeds their final box half-width with exact kNN; returns how many
+  int64_t repair_exact(int k, float start_radius, const int32_t *d_levels, int32_t *d_idx, float *d_dist, hipStream_t s);
   void dbscan(float eps, int min_pts, int32_t *d_labels, uint8_t *d_core, int32_t *d_counts, tknnDbscanInfo *info,
               hipStream_t s);  // dbscan.hip
   bool built() const { return bvh_.built(); }

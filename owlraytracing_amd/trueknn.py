@@ -130,6 +130,18 @@ class TrueKNN:
         out["info"] = self.last_info
         return out
 
+    def repair_exact(self, result, k, start_radius):
+        """Turn the rows of ``solve(..., want_levels=True)`` into exact kNN in place (opt-in; the
+        reference's box-candidate rows are what ``solve`` returns).  Returns the number of rows rewritten."""
+        torch = self._torch
+        n_fixed = ctypes.c_int64(0)
+        with torch.cuda.device(self.device):
+            _lib.check(self._lib.tknnRepairExact(
+                self._h, int(k), ctypes.c_float(start_radius), ctypes.c_void_p(result["levels"].data_ptr()),
+                ctypes.c_void_p(result["idx"].data_ptr()), ctypes.c_void_p(result["dist"].data_ptr()),
+                ctypes.byref(n_fixed), self._stream()))
+        return int(n_fixed.value)
+
     def dbscan(self, eps, min_pts, want_counts=False):
         """RT-DBSCAN over the built tree: dict(labels int32 (n,), core bool (n,), [counts], info)."""
         torch = self._torch
