@@ -8,7 +8,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libowl_mi355x.so")
+LIB_PATH = os.environ.get("OWL_MI355X_LIB") or os.path.join(_HERE, "libowl_mi355x.so")  # override: diagnostic builds
 
 KERNEL_AUTO, KERNEL_LANE, KERNEL_WAVE, KERNEL_TEAM = 0, 1, 2, 3
 MAX_K = 64

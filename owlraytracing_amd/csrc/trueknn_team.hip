@@ -29,7 +29,15 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
+
+// Diagnostic build only (make DIAG=1 -> libowl_mi355x_diag.so, never the shipped library): lets
+// scripts/diag_team.py price the phases by switching them off; results are wrong when any bit is set.
+#ifndef TKNN_DIAG_BUILD
+#define TKNN_DIAG_BUILD 0
+#endif
 
 namespace owlmi {
 
@@ -62,6 +70,7 @@ struct TeamArgs {
   int max_rounds;
   int allow_unfinished;
   int first_step;  // levels the first gather of every packet serves (density estimate, 1..kMaxStep)
+  int diag;        // TKNN_DIAG_BUILD only: 1 skip inserts, 2 skip SELECT passes, 4 skip COUNT passes, 8 skip per-block query tests
   int32_t ngroups;
   int32_t *out_idx;
   float *out_dist;
@@ -223,6 +232,7 @@ __device__ __forceinline__ void team_pass(const TeamArgs &a, const TeamLds &L, i
       if (SELECT) {
         const float d2 = knn_dist2(p.x, p.y, p.z, t_qx, t_qy, t_qz);
         bool pend = in && !is_self && (d2 <= tau2);
+        if (TKNN_DIAG_BUILD && (a.diag & 1)) pend = false;
         unsigned long long pm = __ballot(pend);
         if (pm) {
           // exact key of my candidate, then one team-parallel sorted insert per pending lane
@@ -321,6 +331,19 @@ __global__ void __launch_bounds__(kTeamBlock) team_kernel(TeamArgs a) {
   int wave_levels = 0, wave_err = 0;
   unsigned long long my_handed = 0;
   int wave_min_handover = 0x7fffffff;
+#if TKNN_DIAG_BUILD
+  unsigned long long ph[5] = {0, 0, 0, 0, 0}, t_mark = __builtin_amdgcn_s_memtime();
+#define PHASE_END(i)                                         \
+  do {                                                       \
+    const unsigned long long now_ = __builtin_amdgcn_s_memtime(); \
+    ph[i] += now_ - t_mark;                                  \
+    t_mark = now_;                                           \
+  } while (0)
+#else
+#define PHASE_END(i) \
+  do {               \
+  } while (0)
+#endif
 
   for (;;) {
     int g = 0;
@@ -347,6 +370,7 @@ __global__ void __launch_bounds__(kTeamBlock) team_kernel(TeamArgs a) {
     L.qlist = qlist;
 
     for (;;) {  // radius levels
+      PHASE_END(4);
       // ---- 1. thresholds, query records ----------------------------------------------------
       // This step serves levels level .. level+m-1 with ONE gather at the outermost radius.
       int m = step < 1 ? 1 : (step > kMaxStep ? kMaxStep : step);
@@ -387,6 +411,7 @@ __global__ void __launch_bounds__(kTeamBlock) team_kernel(TeamArgs a) {
       const float g_lo_x = t_wave_min(lo_x), g_lo_y = t_wave_min(lo_y), g_lo_z = t_wave_min(lo_z);
       const float g_hi_x = t_wave_max(hi_x), g_hi_y = t_wave_max(hi_y), g_hi_z = t_wave_max(hi_z);
 
+      PHASE_END(0);
       // ---- 2+3. gather the packet's block list and the per-query masks ----------------------
       int my_nblk = 0;  // lane = query: how many blocks of the packet's list I need
       int my_own_pos = 0;  // ... and where my own block (the one holding me) sits in my list
@@ -427,8 +452,9 @@ __global__ void __launch_bounds__(kTeamBlock) team_kernel(TeamArgs a) {
               om &= om - 1;
               const float b_lo_x = t_bcast(bx.lo[0], src), b_lo_y = t_bcast(bx.lo[1], src), b_lo_z = t_bcast(bx.lo[2], src);
               const float b_hi_x = t_bcast(bx.hi[0], src), b_hi_y = t_bcast(bx.hi[1], src), b_hi_z = t_bcast(bx.hi[2], src);
-              const bool need = (b_lo_x <= hi_x) & (b_hi_x >= lo_x) & (b_lo_y <= hi_y) & (b_hi_y >= lo_y) &
-                                (b_lo_z <= hi_z) & (b_hi_z >= lo_z);
+              bool need = (b_lo_x <= hi_x) & (b_hi_x >= lo_x) & (b_lo_y <= hi_y) & (b_hi_y >= lo_y) &
+                          (b_lo_z <= hi_z) & (b_hi_z >= lo_z);
+              if (TKNN_DIAG_BUILD && (a.diag & 8)) need = false;
               if (__ballot(need) == 0ull) continue;
               if (nb >= kMaxBlocks) {
                 too_big = true;  // more blocks than a byte slot can name
@@ -461,6 +487,7 @@ __global__ void __launch_bounds__(kTeamBlock) team_kernel(TeamArgs a) {
       qrec[lane * kQrecStride + 11] = __int_as_float(my_nblk);  // read back by the teams
       qrec[lane * kQrecStride + 19] = __int_as_float(my_own_pos);
 
+      PHASE_END(1);
       // ---- 4. passes ---------------------------------------------------------------------------
       // One-level step: the box grows 8x per level, so a query with a few others at the previous
       // level will almost surely reach k now and goes straight to the fused count+select pass; the
@@ -476,9 +503,10 @@ __global__ void __launch_bounds__(kTeamBlock) team_kernel(TeamArgs a) {
         const unsigned long long cm = __ballot(count_first);
         if (count_first) qlist[t_rank(cm)] = lane;
         t_wave_sync();
-        team_pass<false, HALO>(a, L, __popcll(cm), level, m, own_pts, halo_pts, lane);
+        if (!(TKNN_DIAG_BUILD && (a.diag & 4))) team_pass<false, HALO>(a, L, __popcll(cm), level, m, own_pts, halo_pts, lane);
         t_wave_sync();
       }
+      PHASE_END(2);
       // first level of the step at which I have >= k others (deviceCode.cu:118), -1 if none
       uint32_t c0 = 0, c1 = 0, c2 = 0, selfc = 0;
       int fin_at = -1;
@@ -509,9 +537,10 @@ __global__ void __launch_bounds__(kTeamBlock) team_kernel(TeamArgs a) {
         t_wave_sync();
         if (select_now) qlist[t_rank(sm)] = lane;
         t_wave_sync();
-        team_pass<true, HALO>(a, L, __popcll(sm), level, 1, own_pts, halo_pts, lane);
+        if (!(TKNN_DIAG_BUILD && (a.diag & 2))) team_pass<true, HALO>(a, L, __popcll(sm), level, 1, own_pts, halo_pts, lane);
         t_wave_sync();
       }
+      PHASE_END(3);
       bool finished = fin_at >= 0;
       uint32_t last_others = 0;
       if (speculate) {
@@ -574,6 +603,9 @@ __global__ void __launch_bounds__(kTeamBlock) team_kernel(TeamArgs a) {
       atomicMin(&a.counters[9], (unsigned long long)wave_min_handover);
     }
     if (wave_err) atomicOr(&a.counters[5], (unsigned long long)wave_err);
+#if TKNN_DIAG_BUILD
+    for (int i = 0; i < 5; i++) atomicAdd(&a.counters[10 + i], ph[i]);
+#endif
   }
 }
 
@@ -619,6 +651,9 @@ bool Engine::solve_team(const SolveArgs &sa, tknnSolveInfo *info, hipStream_t s)
   a.max_rounds = sa.max_rounds;
   a.allow_unfinished = sa.allow_unfinished ? 1 : 0;
   a.first_step = first_step_estimate(sa);
+  a.diag = 0;
+  if (TKNN_DIAG_BUILD)
+    if (const char *d = getenv("TKNN_TEAM_DIAG")) a.diag = atoi(d);
   a.ngroups = (int32_t)((n + 63) / 64);
   a.out_idx = sa.d_idx;
   a.out_dist = sa.d_dist;
@@ -655,6 +690,15 @@ bool Engine::solve_team(const SolveArgs &sa, tknnSolveInfo *info, hipStream_t s)
   OWLMI_HIP(hipStreamSynchronize(s));
   float ms = 0;
   OWLMI_HIP(hipEventElapsedTime(&ms, ev_a_, ev_b_));
+#if TKNN_DIAG_BUILD
+  if (getenv("TKNN_TEAM_DIAG")) {
+    unsigned long long t[5];
+    OWLMI_HIP(hipMemcpy(t, counters_ + 10, sizeof t, hipMemcpyDeviceToHost));
+    const double tot = (double)(t[0] + t[1] + t[2] + t[3] + t[4]);
+    fprintf(stderr, "[team diag] wave-time shares: thresholds %.1f%%  gather %.1f%%  count %.1f%%  select %.1f%%  rest %.1f%%\n",
+            100 * t[0] / tot, 100 * t[1] / tot, 100 * t[2] / tot, 100 * t[3] / tot, 100 * t[4] / tot);
+  }
+#endif
   if (h_counters_[5] & 1ull) throw RoundsExceeded{};
   if (info) {
     const int rounds = (int)h_counters_[1];
