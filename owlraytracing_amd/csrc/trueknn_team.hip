@@ -130,6 +130,13 @@ __device__ __forceinline__ uint32_t t_team_shr1(uint32_t v, uint32_t fill) {
   return (uint32_t)__builtin_amdgcn_update_dpp((int)fill, (int)v, 0x111 /*row_shr:1*/, 0xf, 0xf, false);
 }
 
+// closed-box test lo <= p <= hi on all three axes; requires lo <= hi.  NaN in p gives false.
+__device__ __forceinline__ bool t_in_box(float px, float py, float pz, float lx, float ly, float lz, float hx, float hy,
+                                         float hz) {
+  return (__builtin_amdgcn_fmed3f(px, lx, hx) == px) & (__builtin_amdgcn_fmed3f(py, ly, hy) == py) &
+         (__builtin_amdgcn_fmed3f(pz, lz, hz) == pz);
+}
+
 // one leaf block = LBVH_BLOCK sorted points, 16 bytes each; lane tl of a team reads point tl.
 // The sorted arrays are padded with NaN sentinels to whole blocks (lbvh.hip), so no bounds test.
 template <bool HALO>
@@ -207,28 +214,16 @@ __device__ __forceinline__ void team_pass(const TeamArgs &a, const TeamLds &L, i
     uint32_t cnt = 0, self = 0;
     uint32_t best_d = 0x7f7fffffu, best_i = 0u;  // KNN_EMPTY_KEY = {FLT_MAX, 0}
     float tau2 = INFINITY;
-    // two blocks in flight ahead of the one being tested; loads are unconditional so the compiler
-    // can wait with a counted vmcnt instead of draining
-    LbvhPoint pa = load_block_point<HALO>(own_pts, halo_pts, entry_at(0));
-    LbvhPoint pb = load_block_point<HALO>(own_pts, halo_pts, entry_at(1));
-    for (int it = 0; it < steps; it++) {
-      const LbvhPoint pc = load_block_point<HALO>(own_pts, halo_pts, entry_at(it + 2));
-      LbvhPoint p = pa;
+    // one block's test; `it` is wave-uniform
+    auto process = [&](LbvhPoint p, int it) {
       if (it >= my_n) p.x = qnan;  // past the end of my list (or no query): fails every comparison
-      // lo <= p <= hi on all axes, as "largest signed excess <= 0": the sign of a fp32 difference is
-      // exact, NaN (sentinels, list overrun) propagates to a false compare, and the whole test is
-      // 6 subtractions + 2 max3 + 1 max + 1 compare instead of a chain of mask operations
-      const float ex_lo = fmaxf(fmaxf(t_lx - p.x, t_ly - p.y), t_lz - p.z);
-      const float ex_hi = fmaxf(fmaxf(p.x - t_hx, p.y - t_hy), p.z - t_hz);
-      const bool in = fmaxf(ex_lo, ex_hi) <= 0.f && p.x == p.x;
+      // lo <= p <= hi per axis as "the median of (p, lo, hi) is p" (lo <= hi: a query lies in its own
+      // box): one v_med3 + one compare per axis; NaN (sentinels, list overrun) never compares equal
+      const bool in = t_in_box(p.x, p.y, p.z, t_lx, t_ly, t_lz, t_hx, t_hy, t_hz);
       const bool is_self = in && (p.id == t_qid);  // ids are unique and a query lies in its own box
       cnt += in ? 1u : 0u;
       self += is_self ? 1u : 0u;
-      if (!SELECT && m > 1) {
-        const float a_lo = fmaxf(fmaxf(i0_lx - p.x, i0_ly - p.y), i0_lz - p.z);
-        const float a_hi = fmaxf(fmaxf(p.x - i0_hx, p.y - i0_hy), p.z - i0_hz);
-        cnt_i0 += (fmaxf(a_lo, a_hi) <= 0.f && in) ? 1u : 0u;
-      }
+      if (!SELECT && m > 1) cnt_i0 += t_in_box(p.x, p.y, p.z, i0_lx, i0_ly, i0_lz, i0_hx, i0_hy, i0_hz) ? 1u : 0u;
       if (SELECT) {
         const float d2 = knn_dist2(p.x, p.y, p.z, t_qx, t_qy, t_qz);
         bool pend = in && !is_self && (d2 <= tau2);
@@ -264,8 +259,17 @@ __device__ __forceinline__ void team_pass(const TeamArgs &a, const TeamLds &L, i
           tau2 = knn_gate_from_worst(w);
         }
       }
-      pa = pb;
-      pb = pc;
+    };
+    // ping-pong over two named buffers: the next block is in flight while this one is tested, and
+    // no register is copied between iterations.  Loads are unconditional (clamped index).
+    LbvhPoint pa = load_block_point<HALO>(own_pts, halo_pts, entry_at(0));
+    for (int it = 0; it < steps; it += 2) {
+      const LbvhPoint pb = load_block_point<HALO>(own_pts, halo_pts, entry_at(it + 1));
+      process(pa, it);
+      if (it + 1 < steps) {
+        pa = load_block_point<HALO>(own_pts, halo_pts, entry_at(it + 2));
+        process(pb, it + 1);
+      }
     }
     cnt = t_team_sum(cnt);
     self = t_team_sum(self);
