@@ -205,11 +205,8 @@ __device__ __forceinline__ void team_pass(const TeamArgs &a, const TeamLds &L, i
       if (last >= 64) e4 = L.blk[mine[list_pos(tl + 64)]];
       if (last >= 80) e5 = L.blk[mine[list_pos(tl + 80)]];
     }
-    auto entry_at = [&](int it) -> int32_t {  // `it` is wave-uniform
-      const int c = it < kMaxPerQuery ? it : kMaxPerQuery - 1;
-      const int j = c >> 4;
-      const int32_t v = j == 0 ? e0 : (j == 1 ? e1 : (j == 2 ? e2 : (j == 3 ? e3 : (j == 4 ? e4 : e5))));
-      return (int32_t)t_lane_read((uint32_t)v, (team << 4) + (c & 15));
+    auto entry_reg = [&](int j) -> int32_t {  // j is wave-uniform
+      return j == 0 ? e0 : (j == 1 ? e1 : (j == 2 ? e2 : (j == 3 ? e3 : (j == 4 ? e4 : e5))));
     };
     uint32_t cnt = 0, self = 0;
     uint32_t best_d = 0x7f7fffffu, best_i = 0u;  // KNN_EMPTY_KEY = {FLT_MAX, 0}
@@ -261,14 +258,26 @@ __device__ __forceinline__ void team_pass(const TeamArgs &a, const TeamLds &L, i
       }
     };
     // ping-pong over two named buffers: the next block is in flight while this one is tested, and
-    // no register is copied between iterations.  Loads are unconditional (clamped index).
-    LbvhPoint pa = load_block_point<HALO>(own_pts, halo_pts, entry_at(0));
-    for (int it = 0; it < steps; it += 2) {
-      const LbvhPoint pb = load_block_point<HALO>(own_pts, halo_pts, entry_at(it + 1));
-      process(pa, it);
-      if (it + 1 < steps) {
-        pa = load_block_point<HALO>(own_pts, halo_pts, entry_at(it + 2));
-        process(pb, it + 1);
+    // no register is copied between iterations.  Loads are unconditional (indices past the list
+    // name some valid block, see above).  The list is walked in chunks of 16 entries = one entry
+    // register, so picking the register (a scalar branch chain) happens once per chunk and an
+    // entry costs one select + one cross-lane read.
+    LbvhPoint pa = load_block_point<HALO>(own_pts, halo_pts, (int32_t)t_lane_read((uint32_t)e0, team << 4));
+    for (int base = 0; base < steps; base += 16) {
+      const int j = base >> 4;
+      const int32_t ecur = entry_reg(j), enext = entry_reg(j < 5 ? j + 1 : 5);
+      auto entry_at = [&](int it) -> int32_t {  // base < it <= base + 17, wave-uniform
+        const int c = it - base;
+        return (int32_t)t_lane_read((uint32_t)(c >= 16 ? enext : ecur), (team << 4) + (c & 15));
+      };
+      const int end = min(base + 16, steps);
+      for (int it = base; it < end; it += 2) {
+        const LbvhPoint pb = load_block_point<HALO>(own_pts, halo_pts, entry_at(it + 1));
+        process(pa, it);
+        if (it + 1 < end) {
+          pa = load_block_point<HALO>(own_pts, halo_pts, entry_at(it + 2));
+          process(pb, it + 1);
+        }
       }
     }
     cnt = t_team_sum(cnt);
