@@ -45,23 +45,30 @@ namespace {
 
 constexpr int kTeamBlock = 64;      // one wave per workgroup: LDS, not the block shape, limits residency
 constexpr int kMaxBlocks = 256;     // leaf blocks one packet may need per level (slot fits a byte)
-constexpr int kMaxPerQuery = 96;    // leaf blocks one query may need per level
-constexpr int kTeamStack = 256;     // wide-pyramid stack entries per wave
-constexpr int kQrecStride = 20;     // floats per LDS query record (layout below)
-constexpr int kMaxStep = 2;          // radius levels one gather may serve
-// LDS per wave: query records | block list | per-query block lists | counts | query list | stack
+#ifndef TKNN_MAX_PER_QUERY
+#define TKNN_MAX_PER_QUERY 96
+#endif
+constexpr int kMaxPerQuery = TKNN_MAX_PER_QUERY;  // leaf blocks one query may need per level
+constexpr int kTeamStack = 192;     // wide-pyramid stack entries per wave
+constexpr int kQrecStride = 12;     // floats per LDS query record (layout below)
+constexpr int kMaxStep = 2;          // radius levels one gather may serve (the count slots and the inner-box test assume <= 2)
+// LDS per wave: query records | block list | per-query block lists | counts, query list / stack.
+// The pyramid stack is live only during the gather, the counts and the query list only during the
+// passes, so they share one region.  Every KB counts: LDS, not registers, limits residency.
 constexpr int kLdsQrec = 64 * kQrecStride * 4;
 constexpr int kLdsBlk = kMaxBlocks * 4;
 constexpr int kLdsMask = 64 * kMaxPerQuery;  // per-query lists of block slots (bytes)
-constexpr int kLdsCnt = 64 * 4 * 4 + 64 * 8;  // {cnt[3], self} per query + isect before the chosen level
+constexpr int kLdsCnt = 64 * 2 * 4;  // per query: candidates at the inner level, at the outer level | self << 31
 constexpr int kLdsList = 64 * 4;
 constexpr int kLdsStack = kTeamStack * 4;
-constexpr int kTeamLds = kLdsQrec + kLdsBlk + kLdsMask + kLdsCnt + kLdsList + kLdsStack;
+constexpr int kLdsShared = (kLdsCnt + kLdsList) > kLdsStack ? (kLdsCnt + kLdsList) : kLdsStack;
+constexpr int kTeamLds = kLdsQrec + kLdsBlk + kLdsMask + kLdsShared;
 
 // LDS query record: [0..2] q, [3] id, [4..9] thresholds of the box the pass works in (outermost
-// level of the step for COUNT, the finishing level for SELECT), [10] row, [11] #blocks,
-// [12..17] thresholds of the inner level of a two-level step, [18] level reported with the row,
-// [19] position of the query's own block in its list
+// level of the step for COUNT, the finishing level for SELECT), [10] row, [11] packed: #blocks |
+// position of the query's own block in its list << 8.  The inner box of a two-level COUNT step is
+// tested literally (deviceCode.cu:38-56 as written) from the query and the inner radius instead of
+// through stored thresholds: 6 more instructions per block in that pass, 1.5 KB less LDS per wave.
 struct TeamArgs {
   LbvhView bvh, halo;
   LbvhWideView wide[2];
@@ -149,8 +156,7 @@ struct TeamLds {
   float *qrec;        // [64][kQrecStride]
   int32_t *blk;       // [kMaxBlocks] block entries of the packet (bit 31: halo tree)
   uint8_t *qblk;      // [64][kMaxPerQuery] per-query slots into blk[]
-  uint32_t *qcnt;     // [64][2] out: candidates in box, others
-  uint64_t *qis;      // [64] intersections accumulated before this level
+  uint32_t *qcnt;     // [64][2] out: candidates in the inner box, in the outer box | self << 31
   int32_t *qlist;     // compact list of the queries this pass serves
 };
 
@@ -158,7 +164,7 @@ struct TeamLds {
 // (deviceCode.cu:74,103).  SELECT = true: also keep the k best (dist,index) keys, lane j of the
 // team holding the j-th, and write the row if the query turns out finished (>= k others).
 template <bool SELECT, bool HALO>
-__device__ __forceinline__ void team_pass(const TeamArgs &a, const TeamLds &L, int n_list, int level, int m,
+__device__ __forceinline__ void team_pass(const TeamArgs &a, const TeamLds &L, int n_list, float r_inner, int m,
                                           const LbvhPoint *own_pts, const LbvhPoint *halo_pts, int lane) {
   const int team = lane >> 4, tl = lane & 15;
   const float qnan = __uint_as_float(0x7fc00000u);
@@ -170,10 +176,9 @@ __device__ __forceinline__ void team_pass(const TeamArgs &a, const TeamLds &L, i
     const float t_qx = rec[0], t_qy = rec[1], t_qz = rec[2];
     const int32_t t_qid = __float_as_int(rec[3]);
     const float t_lx = rec[4], t_ly = rec[5], t_lz = rec[6], t_hx = rec[7], t_hy = rec[8], t_hz = rec[9];
-    // inner levels of a multi-level COUNT step (m = levels served by this gather, wave-uniform)
-    const float i0_lx = rec[12], i0_ly = rec[13], i0_lz = rec[14], i0_hx = rec[15], i0_hy = rec[16], i0_hz = rec[17];
-    uint32_t cnt_i0 = 0;
-    const int my_n = on ? __float_as_int(rec[11]) : 0;  // leaf blocks of my team's query
+    uint32_t cnt_i0 = 0;  // inner level of a two-level COUNT step (m = levels served by this gather, wave-uniform)
+    const int packed = __float_as_int(rec[11]);
+    const int my_n = on ? (packed & 0xff) : 0;  // leaf blocks of my team's query
     int steps = my_n;                                   // wave-uniform trip count: longest list of the 4 teams
     steps = max(steps, (int)__builtin_amdgcn_readlane(my_n, 16));
     steps = max(steps, (int)__builtin_amdgcn_readlane(my_n, 32));
@@ -188,7 +193,7 @@ __device__ __forceinline__ void team_pass(const TeamArgs &a, const TeamLds &L, i
     // Blocks are visited outward from the query's own block, alternating sides of its Morton-ordered
     // list: near blocks first tightens the k-th-distance gate early (about 30 % fewer inserts than
     // list order on uniform data) and changes nothing else -- the result does not depend on order.
-    const int own_pos = on ? __float_as_int(rec[19]) : 0;
+    const int own_pos = on ? ((packed >> 8) & 0xff) : 0;
     const int left = own_pos, right = last - own_pos, both = min(left, right);
     auto list_pos = [&](int it) -> int {
       if (it > last) it = last;
@@ -220,7 +225,7 @@ __device__ __forceinline__ void team_pass(const TeamArgs &a, const TeamLds &L, i
       const bool is_self = in && (p.id == t_qid);  // ids are unique and a query lies in its own box
       cnt += in ? 1u : 0u;
       self += is_self ? 1u : 0u;
-      if (!SELECT && m > 1) cnt_i0 += t_in_box(p.x, p.y, p.z, i0_lx, i0_ly, i0_lz, i0_hx, i0_hy, i0_hz) ? 1u : 0u;
+      if (!SELECT && m > 1) cnt_i0 += knn_in_box(p.x, p.y, p.z, r_inner, t_qx, t_qy, t_qz) ? 1u : 0u;
       if (SELECT) {
         const float d2 = knn_dist2(p.x, p.y, p.z, t_qx, t_qy, t_qz);
         bool pend = in && !is_self && (d2 <= tau2);
@@ -286,17 +291,18 @@ __device__ __forceinline__ void team_pass(const TeamArgs &a, const TeamLds &L, i
     if (!SELECT && m > 1) cnt_i0 = t_team_sum(cnt_i0);
     if (on && tl == 0) {
       // counts innermost level first; a one-level pass fills slot 0
-      uint32_t *out = L.qcnt + qi * 4;
+      uint32_t *out = L.qcnt + qi * 2;
       if (SELECT || m == 1) {
         out[0] = cnt;
+        out[1] = self << 31;
       } else {
         out[0] = cnt_i0;
-        out[1] = cnt;
+        out[1] = cnt | (self << 31);
       }
-      out[3] = self;
     }
     if (SELECT) {
-      // finished at this level (deviceCode.cu:118: k insertions happened): lane j < k stores neighbour j
+      // finished at this level (deviceCode.cu:118: k insertions happened): lane j < k stores neighbour j.
+      // The query's own lane adds the intersection count and the level afterwards (team_kernel).
       if (on && others >= (uint32_t)a.k && tl < a.k) {
         const int32_t out_row = __float_as_int(rec[10]);
         const int64_t o = (int64_t)out_row * a.k + tl;
@@ -305,19 +311,12 @@ __device__ __forceinline__ void team_pass(const TeamArgs &a, const TeamLds &L, i
         const float d = __uint_as_float(best_d);
         if (a.out_idx) a.out_idx[o] = prim;
         if (a.out_dist) a.out_dist[o] = d;
-        const int64_t tot = (int64_t)(L.qis[qi] + cnt);
         if (a.out_fb) {
-          tknnNeigh ev;
-          ev.ind = prim;
-          ev.dist = d;
-          ev.numNeighbors = tl == 0 ? 0 : a.k;
-          ev.pad_ = 0;
-          ev.intersections = tl == 0 ? tot : 0;
-          a.out_fb[o] = ev;
-        }
-        if (tl == 0) {
-          if (a.out_isect) a.out_isect[out_row] = tot;
-          if (a.out_level) a.out_level[out_row] = SELECT ? __float_as_int(rec[18]) : level;
+          // slot 0 of the row: everything but `intersections`, which only the query's lane writes
+          int2 *rec8 = (int2 *)(a.out_fb + o);
+          rec8[0] = make_int2(prim, __float_as_int(d));
+          rec8[1] = make_int2(tl == 0 ? 0 : a.k, 0);
+          if (tl != 0) rec8[2] = make_int2(0, 0);
         }
       }
     }
@@ -335,9 +334,8 @@ __global__ void __launch_bounds__(kTeamBlock) team_kernel(TeamArgs a) {
   int32_t *blk = (int32_t *)(base + kLdsQrec);
   uint8_t *qblk = (uint8_t *)(base + kLdsQrec + kLdsBlk);  // [query][kMaxPerQuery] slots into blk[]
   uint32_t *qcnt = (uint32_t *)(base + kLdsQrec + kLdsBlk + kLdsMask);
-  uint64_t *qis = (uint64_t *)(base + kLdsQrec + kLdsBlk + kLdsMask + 64 * 4 * 4);
   int32_t *qlist = (int32_t *)(base + kLdsQrec + kLdsBlk + kLdsMask + kLdsCnt);
-  int32_t *stack = (int32_t *)(base + kLdsQrec + kLdsBlk + kLdsMask + kLdsCnt + kLdsList);
+  int32_t *stack = (int32_t *)(base + kLdsQrec + kLdsBlk + kLdsMask);  // shares the counts / query list region
 
   const LbvhPoint *own_pts = a.bvh.points + tl, *halo_pts = a.halo.points ? a.halo.points + tl : a.bvh.points + tl;
   unsigned long long my_isect_sum = 0, my_levels = 0, my_unfinished = 0, wave_node_tests = 0, wave_point_tests = 0;
@@ -379,7 +377,6 @@ __global__ void __launch_bounds__(kTeamBlock) team_kernel(TeamArgs a) {
     L.blk = blk;
     L.qblk = qblk;
     L.qcnt = qcnt;
-    L.qis = qis;
     L.qlist = qlist;
 
     for (;;) {  // radius levels
@@ -401,14 +398,6 @@ __global__ void __launch_bounds__(kTeamBlock) team_kernel(TeamArgs a) {
           hi_x = thr_hi(q.x, r_out);
           hi_y = thr_hi(q.y, r_out);
           hi_z = thr_hi(q.z, r_out);
-          if (m > 1) {
-            rec[12] = thr_lo(q.x, r_in0);
-            rec[13] = thr_lo(q.y, r_in0);
-            rec[14] = thr_lo(q.z, r_in0);
-            rec[15] = thr_hi(q.x, r_in0);
-            rec[16] = thr_hi(q.y, r_in0);
-            rec[17] = thr_hi(q.z, r_in0);
-          }
         }
         rec[0] = q.x;
         rec[1] = q.y;
@@ -497,8 +486,8 @@ __global__ void __launch_bounds__(kTeamBlock) team_kernel(TeamArgs a) {
         active = false;
         break;
       }
-      qrec[lane * kQrecStride + 11] = __int_as_float(my_nblk);  // read back by the teams
-      qrec[lane * kQrecStride + 19] = __int_as_float(my_own_pos);
+      int my_packed = my_nblk | (my_own_pos << 8);  // read back by the teams; the level is added below
+      qrec[lane * kQrecStride + 11] = __int_as_float(my_packed);
 
       PHASE_END(1);
       // ---- 4. passes ---------------------------------------------------------------------------
@@ -509,56 +498,54 @@ __global__ void __launch_bounds__(kTeamBlock) team_kernel(TeamArgs a) {
       // A row is written only when its query really has >= k others in the chosen box, so neither
       // speculation nor level grouping can change a result.
       qrec[lane * kQrecStride + 10] = __int_as_float(row);
-      qis[lane] = (uint64_t)isect;
       const bool speculate = m == 1 && active && level > 0 && prev_others * 8u >= (uint32_t)(a.k + a.k / 2);
       const bool count_first = active && !speculate;
       {
         const unsigned long long cm = __ballot(count_first);
         if (count_first) qlist[t_rank(cm)] = lane;
         t_wave_sync();
-        if (!(TKNN_DIAG_BUILD && (a.diag & 4))) team_pass<false, HALO>(a, L, __popcll(cm), level, m, own_pts, halo_pts, lane);
+        if (!(TKNN_DIAG_BUILD && (a.diag & 4))) team_pass<false, HALO>(a, L, __popcll(cm), r_in0, m, own_pts, halo_pts, lane);
         t_wave_sync();
       }
       PHASE_END(2);
       // first level of the step at which I have >= k others (deviceCode.cu:118), -1 if none
-      uint32_t c0 = 0, c1 = 0, c2 = 0, selfc = 0;
+      uint32_t c0 = 0, c1 = 0, selfc = 0;
       int fin_at = -1;
       if (count_first) {
-        c0 = qcnt[lane * 4 + 0];
-        c1 = m > 1 ? qcnt[lane * 4 + 1] : 0u;
-        c2 = m > 2 ? qcnt[lane * 4 + 2] : 0u;
-        selfc = qcnt[lane * 4 + 3];
+        c0 = qcnt[lane * 2 + 0];
+        const uint32_t w1 = qcnt[lane * 2 + 1];
+        c1 = m > 1 ? (w1 & 0x7fffffffu) : 0u;
+        selfc = w1 >> 31;
         if (c0 - selfc >= (uint32_t)a.k)
           fin_at = 0;
         else if (m > 1 && c1 - selfc >= (uint32_t)a.k)
           fin_at = 1;
-        else if (m > 2 && c2 - selfc >= (uint32_t)a.k)
-          fin_at = 2;
       }
       const bool select_now = speculate || fin_at >= 0;
-      if (m > 1 && fin_at >= 0 && fin_at < m - 1) {
+      if (m > 1 && fin_at == 0) {
         // finishing inside the step: the SELECT pass works in that inner box
         float *rec = qrec + lane * kQrecStride;
-        const float *src = rec + 12 + 6 * fin_at;
-#pragma unroll
-        for (int j = 0; j < 6; j++) rec[4 + j] = src[j];
+        rec[4] = thr_lo(q.x, r_in0);
+        rec[5] = thr_lo(q.y, r_in0);
+        rec[6] = thr_lo(q.z, r_in0);
+        rec[7] = thr_hi(q.x, r_in0);
+        rec[8] = thr_hi(q.y, r_in0);
+        rec[9] = thr_hi(q.z, r_in0);
       }
-      if (fin_at > 0) qis[lane] = (uint64_t)isect + c0 + (fin_at > 1 ? c1 : 0u);  // levels before the chosen one
-      if (select_now) qrec[lane * kQrecStride + 18] = __int_as_float(level + (fin_at > 0 ? fin_at : 0));  // level reported for the row
       {
         const unsigned long long sm = __ballot(select_now);
         t_wave_sync();
         if (select_now) qlist[t_rank(sm)] = lane;
         t_wave_sync();
-        if (!(TKNN_DIAG_BUILD && (a.diag & 2))) team_pass<true, HALO>(a, L, __popcll(sm), level, 1, own_pts, halo_pts, lane);
+        if (!(TKNN_DIAG_BUILD && (a.diag & 2))) team_pass<true, HALO>(a, L, __popcll(sm), r_in0, 1, own_pts, halo_pts, lane);
         t_wave_sync();
       }
       PHASE_END(3);
       bool finished = fin_at >= 0;
       uint32_t last_others = 0;
       if (speculate) {
-        c0 = qcnt[lane * 4 + 0];
-        selfc = qcnt[lane * 4 + 3];
+        c0 = qcnt[lane * 2 + 0];
+        selfc = qcnt[lane * 2 + 1] >> 31;
         finished = c0 - selfc >= (uint32_t)a.k;
         fin_at = finished ? 0 : -1;
       }
@@ -567,9 +554,8 @@ __global__ void __launch_bounds__(kTeamBlock) team_kernel(TeamArgs a) {
         levels_run = finished ? fin_at + 1 : m;
         isect += c0;
         if (levels_run > 1) isect += c1;
-        if (levels_run > 2) isect += c2;
         my_levels += (unsigned long long)levels_run;
-        last_others = (m > 2 ? c2 : (m > 1 ? c1 : c0)) - selfc;
+        last_others = (m > 1 ? c1 : c0) - selfc;
         prev_others = last_others;
       }
       wave_levels = max(wave_levels, (int)t_wave_max((float)(active ? level + levels_run : 0)));
@@ -578,7 +564,13 @@ __global__ void __launch_bounds__(kTeamBlock) team_kernel(TeamArgs a) {
         const unsigned long long passes = (count_first ? 1ull : 0ull) + (select_now ? 1ull : 0ull);
         wave_point_tests += t_wave_sum(active ? (unsigned long long)my_nblk * LBVH_BLOCK * passes : 0ull);
       }
-      if (finished) my_isect_sum += (unsigned long long)isect;
+      if (finished) {
+        // the team wrote the row (SELECT pass); the counter and the level come from the query's lane
+        my_isect_sum += (unsigned long long)isect;
+        if (a.out_isect) a.out_isect[row] = isect;
+        if (a.out_fb) a.out_fb[(int64_t)row * a.k].intersections = isect;
+        if (a.out_level) a.out_level[row] = level + (fin_at > 0 ? fin_at : 0);
+      }
       active = active && !finished;
       level += m;
       t_wave_sync();
