@@ -423,32 +423,65 @@ __global__ void __launch_bounds__(kTeamBlock) team_kernel(TeamArgs a) {
         const LbvhWideView &wv = a.wide[tree];
         const int32_t tree_n = tree == 0 ? a.bvh.n : a.halo.n;
         if (tree_n <= 0 || wv.levels <= 0) continue;
-        int sp = 1;
-        if (lane == 0) stack[0] = (wv.levels << 26) | 0;  // virtual root above the top level
+        // Depth-first over the inner levels of the pyramid.  Wide nodes whose children are leaf blocks
+        // are not expanded one by one but collected (the list grows down from the top of the stack
+        // array) and drained together: in ascending Morton order, the next node's child boxes in
+        // flight while this node's blocks are tested against the 64 queries.
+        int sp = 0, nleaf = 0;
+        if (lane == 0) stack[wv.levels > 1 ? 0 : kTeamStack - 1] = (wv.levels << 26) | 0;  // virtual root above the top level
+        if (wv.levels > 1)
+          sp = 1;
+        else
+          nleaf = 1;
         t_wave_sync();
-        while (sp > 0 && !too_big) {
-          const int32_t e = __builtin_amdgcn_readfirstlane(stack[sp - 1]);  // same address in every lane
-          sp--;
-          const int lvl = (e >> 26) - 1;    // level of the children
-          const int32_t first_child = (e & 0x3ffffff) * 64;
-          const int32_t c = first_child + lane;
-          const bool valid = lvl == wv.levels - 1 ? (lane < wv.count[lvl] && first_child == 0) : (c < wv.count[lvl]);
-          LbvhBox bx = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
-          if (valid) bx = wv.level[lvl][c];
-          wave_node_tests += 64;
-          const bool ov = valid & (bx.lo[0] <= g_hi_x) & (bx.hi[0] >= g_lo_x) & (bx.lo[1] <= g_hi_y) &
-                          (bx.hi[1] >= g_lo_y) & (bx.lo[2] <= g_hi_z) & (bx.hi[2] >= g_lo_z);
-          unsigned long long om = __ballot(ov);
-          if (lvl > 0) {
-            if (sp + __popcll(om) > kTeamStack) {
-              too_big = true;
-              break;
+        const int32_t last_block = wv.count[0] - 1;
+        while ((sp > 0 || nleaf > 0) && !too_big) {
+          if (sp > 0 && sp + nleaf + 63 <= kTeamStack) {  // room for the 64 children of one more node
+            const int32_t e = __builtin_amdgcn_readfirstlane(stack[sp - 1]);  // same address in every lane
+            sp--;
+            const int lvl = (e >> 26) - 1;    // level of the children (>= 1 here)
+            const int32_t first_child = (e & 0x3ffffff) * 64;
+            const int32_t c = first_child + lane;
+            const bool valid = lvl == wv.levels - 1 ? (lane < wv.count[lvl] && first_child == 0) : (c < wv.count[lvl]);
+            LbvhBox bx = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
+            if (valid) bx = wv.level[lvl][c];
+            wave_node_tests += 64;
+            const bool ov = valid & (bx.lo[0] <= g_hi_x) & (bx.hi[0] >= g_lo_x) & (bx.lo[1] <= g_hi_y) &
+                            (bx.hi[1] >= g_lo_y) & (bx.lo[2] <= g_hi_z) & (bx.hi[2] >= g_lo_z);
+            const unsigned long long om = __ballot(ov);
+            const int cnt = __popcll(om);
+            if (lvl > 1) {
+              if (ov) stack[sp + t_rank(om)] = (lvl << 26) | c;
+              sp += cnt;
+            } else {
+              // children of `c` are leaf blocks; nodes are popped in descending Morton order, so filling
+              // the list downwards in descending rank keeps it ascending in memory
+              if (ov) stack[kTeamStack - 1 - nleaf - (cnt - 1 - t_rank(om))] = (lvl << 26) | c;
+              nleaf += cnt;
             }
-            if (ov) stack[sp + t_rank(om)] = ((lvl) << 26) | c;
-            sp += __popcll(om);
             t_wave_sync();
-          } else {
-            // leaf blocks: which of my 64 queries need block c?
+            continue;
+          }
+          if (nleaf == 0) {  // inner nodes alone fill the stack
+            too_big = true;
+            break;
+          }
+          auto leaf_boxes = [&](int i) -> LbvhBox {  // i-th collected node; index and children clamped
+            const int32_t e = __builtin_amdgcn_readfirstlane(stack[kTeamStack - nleaf + (i < nleaf ? i : nleaf - 1)]);
+            return wv.level[0][min((e & 0x3ffffff) * 64 + lane, last_block)];
+          };
+          LbvhBox bx_next = leaf_boxes(0);
+          for (int i = 0; i < nleaf && !too_big; i++) {
+            const int32_t e = __builtin_amdgcn_readfirstlane(stack[kTeamStack - nleaf + i]);
+            const int32_t first_child = (e & 0x3ffffff) * 64;
+            const LbvhBox bx = bx_next;
+            bx_next = leaf_boxes(i + 1);
+            const bool valid = first_child + lane <= last_block;
+            wave_node_tests += 64;
+            const bool ov = valid & (bx.lo[0] <= g_hi_x) & (bx.hi[0] >= g_lo_x) & (bx.lo[1] <= g_hi_y) &
+                            (bx.hi[1] >= g_lo_y) & (bx.lo[2] <= g_hi_z) & (bx.hi[2] >= g_lo_z);
+            unsigned long long om = __ballot(ov);
+            // leaf blocks: which of my 64 queries need block c?  (lanes = queries, box by v_readlane)
             while (om) {
               const int src = __ffsll((long long)om) - 1;
               om &= om - 1;
@@ -471,7 +504,10 @@ __global__ void __launch_bounds__(kTeamBlock) team_kernel(TeamArgs a) {
               nb++;
             }
           }
+          nleaf = 0;
+          t_wave_sync();
         }
+        t_wave_sync();  // the stack array is rewritten by the next tree / shared with the passes
       }
       if (__ballot(my_nblk > kMaxPerQuery) != 0ull) too_big = true;  // a query needs more blocks than its list holds
       if (too_big) {
