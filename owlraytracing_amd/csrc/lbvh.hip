@@ -148,8 +148,9 @@ __global__ void __launch_bounds__(kBlock) gather_kernel(const float *__restrict_
                                                        const int32_t *__restrict__ ids) {
   int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   if (i >= n) {
-    // sentinels fill the last leaf block: NaN coordinates fail every box comparison
-    if (POINTS && i < (n + LBVH_BLOCK - 1) / LBVH_BLOCK * LBVH_BLOCK) {
+    // sentinels fill the last leaf block and one whole block after it (the team kernel's "no
+    // block" entry): NaN coordinates fail every box comparison
+    if (POINTS && i < (n + LBVH_BLOCK - 1) / LBVH_BLOCK * LBVH_BLOCK + LBVH_BLOCK) {
       LbvhPoint s;
       s.x = s.y = s.z = __uint_as_float(0x7fc00000u);
       s.id = -1;
@@ -376,7 +377,7 @@ void Lbvh::reserve(int64_t n) {
   dev_alloc(split_owner_, (size_t)n, total);
   dev_alloc(rope_node_, (size_t)n, total);
   dev_alloc(rope_leaf_, (size_t)n, total);
-  dev_alloc(points_, (size_t)n + LBVH_BLOCK, total);  // + NaN sentinels up to a whole leaf block
+  dev_alloc(points_, (size_t)n + 2 * LBVH_BLOCK, total);  // + NaN sentinels up to a whole leaf block, + one all-NaN block
   dev_alloc(boxes_, (size_t)n, total);
   dev_alloc(prim_id_, (size_t)n, total);
   int64_t m = n;
@@ -471,7 +472,7 @@ void Lbvh::build_from_points(const float *d_xyz, int64_t n, hipStream_t stream, 
                      (const LbvhBox *)nullptr, n, scene_, codes_, order_);
   OWLMI_HIP(hipGetLastError());
   sort_and_tree(stream);
-  hipLaunchKernelGGL(gather_kernel<true>, dim3(blocks_for(n + LBVH_BLOCK)), dim3(kBlock), 0, stream, d_xyz,
+  hipLaunchKernelGGL(gather_kernel<true>, dim3(blocks_for(n + 2 * LBVH_BLOCK)), dim3(kBlock), 0, stream, d_xyz,
                      (const LbvhBox *)nullptr, n, order_alt_, points_, (LbvhBox *)nullptr, prim_id_, d_ids);
   OWLMI_HIP(hipGetLastError());
   fit(stream);

@@ -144,8 +144,28 @@ __device__ __forceinline__ bool t_in_box(float px, float py, float pz, float lx,
          (__builtin_amdgcn_fmed3f(pz, lz, hz) == pz);
 }
 
+// acc + (flag ? 1 : 0) as ONE add-with-carry on the compare mask (the compiler's select + add is two)
+__device__ __forceinline__ uint32_t t_count(uint32_t acc, bool flag) {
+  const unsigned long long mask = __ballot(flag);
+  uint32_t out;
+  asm("v_addc_co_u32_e64 %0, vcc, 0, %1, %2" : "=v"(out) : "v"(acc), "s"(mask) : "vcc");
+  return out;
+}
+
+// squared distance, knn_dist2's expression ((x*x) + (y*y)) + (z*z) with x and y in one packed lane pair
+typedef float t_float2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float t_dist2(float px, float py, float pz, float qx, float qy, float qz) {
+#pragma clang fp contract(off)
+  const t_float2 pxy = {px, py}, qxy = {qx, qy};
+  const t_float2 dxy = pxy - qxy;
+  const t_float2 sq = dxy * dxy;
+  const float dz = pz - qz;
+  return (sq.x + sq.y) + (dz * dz);
+}
+
 // one leaf block = LBVH_BLOCK sorted points, 16 bytes each; lane tl of a team reads point tl.
-// The sorted arrays are padded with NaN sentinels to whole blocks (lbvh.hip), so no bounds test.
+// The sorted arrays are padded with NaN sentinels to whole blocks and followed by one all-NaN block
+// (lbvh.hip), so there is no bounds test and "no block" is an ordinary entry.
 template <bool HALO>
 __device__ __forceinline__ LbvhPoint load_block_point(const LbvhPoint *own, const LbvhPoint *halo, int32_t entry) {
   const LbvhPoint *base = (HALO && entry < 0) ? halo : own;
@@ -167,7 +187,6 @@ template <bool SELECT, bool HALO>
 __device__ __forceinline__ void team_pass(const TeamArgs &a, const TeamLds &L, int n_list, float r_inner, int m,
                                           const LbvhPoint *own_pts, const LbvhPoint *halo_pts, int lane) {
   const int team = lane >> 4, tl = lane & 15;
-  const float qnan = __uint_as_float(0x7fc00000u);
   for (int r0 = 0; r0 < n_list; r0 += 4) {
     const bool on = r0 + team < n_list;
     int qi = 0;
@@ -189,45 +208,47 @@ __device__ __forceinline__ void team_pass(const TeamArgs &a, const TeamLds &L, i
     const uint8_t *mine = L.qblk + qi * kMaxPerQuery;
     const int last = my_n - 1;
     static_assert(kMaxPerQuery <= 96, "entry registers below are written out for 6 x 16 entries");
-    int32_t e0 = 0, e1 = 0, e2 = 0, e3 = 0, e4 = 0, e5 = 0;  // named, not an array: must stay in VGPRs
+    // positions past the end of my list (and teams without a query) name the all-NaN block after
+    // the own tree's last block: its points fail every test, so the loop needs no "am I still in
+    // my list" check
+    const int32_t nan_block = a.wide[0].count[0];
+    int32_t e0 = nan_block, e1 = nan_block, e2 = nan_block, e3 = nan_block, e4 = nan_block, e5 = nan_block;  // named, not an array: must stay in VGPRs
     // Blocks are visited outward from the query's own block, alternating sides of its Morton-ordered
     // list: near blocks first tightens the k-th-distance gate early (about 30 % fewer inserts than
     // list order on uniform data) and changes nothing else -- the result does not depend on order.
     const int own_pos = on ? ((packed >> 8) & 0xff) : 0;
     const int left = own_pos, right = last - own_pos, both = min(left, right);
     auto list_pos = [&](int it) -> int {
-      if (it > last) it = last;
       if (it == 0) return own_pos;
       if (it <= 2 * both) return (it & 1) ? own_pos + ((it + 1) >> 1) : own_pos - (it >> 1);
       const int far = it - both;
       return right > left ? own_pos + far : own_pos - far;
     };
+    auto list_entry = [&](int pos) -> int32_t { return pos <= last ? L.blk[mine[list_pos(pos)]] : nan_block; };
     if (my_n > 0) {
-      e0 = L.blk[mine[list_pos(tl)]];
-      if (last >= 16) e1 = L.blk[mine[list_pos(tl + 16)]];
-      if (last >= 32) e2 = L.blk[mine[list_pos(tl + 32)]];
-      if (last >= 48) e3 = L.blk[mine[list_pos(tl + 48)]];
-      if (last >= 64) e4 = L.blk[mine[list_pos(tl + 64)]];
-      if (last >= 80) e5 = L.blk[mine[list_pos(tl + 80)]];
+      e0 = list_entry(tl);
+      if (last >= 16) e1 = list_entry(tl + 16);
+      if (last >= 32) e2 = list_entry(tl + 32);
+      if (last >= 48) e3 = list_entry(tl + 48);
+      if (last >= 64) e4 = list_entry(tl + 64);
+      if (last >= 80) e5 = list_entry(tl + 80);
     }
     auto entry_reg = [&](int j) -> int32_t {  // j is wave-uniform
       return j == 0 ? e0 : (j == 1 ? e1 : (j == 2 ? e2 : (j == 3 ? e3 : (j == 4 ? e4 : e5))));
     };
-    uint32_t cnt = 0, self = 0;
+    uint32_t cnt = 0;
     uint32_t best_d = 0x7f7fffffu, best_i = 0u;  // KNN_EMPTY_KEY = {FLT_MAX, 0}
     float tau2 = INFINITY;
     // one block's test; `it` is wave-uniform
-    auto process = [&](LbvhPoint p, int it) {
-      if (it >= my_n) p.x = qnan;  // past the end of my list (or no query): fails every comparison
+    auto process = [&](const LbvhPoint &p) {
       // lo <= p <= hi per axis as "the median of (p, lo, hi) is p" (lo <= hi: a query lies in its own
       // box): one v_med3 + one compare per axis; NaN (sentinels, list overrun) never compares equal
       const bool in = t_in_box(p.x, p.y, p.z, t_lx, t_ly, t_lz, t_hx, t_hy, t_hz);
       const bool is_self = in && (p.id == t_qid);  // ids are unique and a query lies in its own box
-      cnt += in ? 1u : 0u;
-      self += is_self ? 1u : 0u;
-      if (!SELECT && m > 1) cnt_i0 += knn_in_box(p.x, p.y, p.z, r_inner, t_qx, t_qy, t_qz) ? 1u : 0u;
+      cnt = t_count(cnt, in);
+      if (!SELECT && m > 1) cnt_i0 = t_count(cnt_i0, knn_in_box(p.x, p.y, p.z, r_inner, t_qx, t_qy, t_qz));
       if (SELECT) {
-        const float d2 = knn_dist2(p.x, p.y, p.z, t_qx, t_qy, t_qz);
+        const float d2 = t_dist2(p.x, p.y, p.z, t_qx, t_qy, t_qz);
         bool pend = in && !is_self && (d2 <= tau2);
         if (TKNN_DIAG_BUILD && (a.diag & 1)) pend = false;
         unsigned long long pm = __ballot(pend);
@@ -278,15 +299,15 @@ __device__ __forceinline__ void team_pass(const TeamArgs &a, const TeamLds &L, i
       const int end = min(base + 16, steps);
       for (int it = base; it < end; it += 2) {
         const LbvhPoint pb = load_block_point<HALO>(own_pts, halo_pts, entry_at(it + 1));
-        process(pa, it);
+        process(pa);
         if (it + 1 < end) {
           pa = load_block_point<HALO>(own_pts, halo_pts, entry_at(it + 2));
-          process(pb, it + 1);
+          process(pb);
         }
       }
     }
     cnt = t_team_sum(cnt);
-    self = t_team_sum(self);
+    const uint32_t self = cnt ? 1u : 0u;  // a query lies in its own box, and ids are unique
     const uint32_t others = cnt - self;
     if (!SELECT && m > 1) cnt_i0 = t_team_sum(cnt_i0);
     if (on && tl == 0) {
@@ -324,7 +345,7 @@ __device__ __forceinline__ void team_pass(const TeamArgs &a, const TeamLds &L, i
 }
 
 template <bool HALO>
-__global__ void __launch_bounds__(kTeamBlock) team_kernel(TeamArgs a) {
+__global__ void __launch_bounds__(kTeamBlock) __attribute__((amdgpu_waves_per_eu(4))) team_kernel(TeamArgs a) {
   extern __shared__ __align__(16) unsigned char smem[];
   const int lane = threadIdx.x & 63;
   const int wid = threadIdx.x >> 6;  // 0 with one wave per workgroup
