@@ -165,6 +165,9 @@ __global__ void __launch_bounds__(kBlock) gather_kernel(const float *__restrict_
     p.x = xyz[3 * (int64_t)src];
     p.y = xyz[3 * (int64_t)src + 1];
     p.z = xyz[3 * (int64_t)src + 2];
+    // a point with any NaN coordinate is nobody's candidate (every closed-box comparison with NaN is
+    // false) and finds none; store it as all-NaN so that kernels may test |c - q| per axis first
+    if (p.x != p.x || p.y != p.y || p.z != p.z) p.x = p.y = p.z = __uint_as_float(0x7fc00000u);
     p.id = ids ? ids[src] : (int32_t)src;
     points[i] = p;
   } else {

@@ -8,12 +8,12 @@
 // one coalesced 256-byte read) of that query's OWN block list.
 //
 // Per packet of 64 Morton-consecutive queries and per radius level (hostCode.cpp:285-340 rounds):
-//   1. lanes = queries: exact candidate thresholds (as in the wave kernel) -> LDS query records.
+//   1. lanes = queries: LDS query records and conservative query boxes for the gather.
 //   2. lanes = child boxes: the wave walks the 64-ary block pyramid (LbvhWideView) depth-first
 //      with an LDS stack, one wide node per step, against the union box of the packet.
 //   3. every surviving leaf block is tested against the 64 individual query boxes
 //      (lanes = queries again, block box broadcast by v_readlane); blocks some query needs are
-//      appended to the packet's block list and recorded in per-query bit masks (ballot, no atomics).
+//      appended to the packet's block list and to the per-query lists of byte slots (no atomics).
 //   4. COUNT pass, teams over the compacted list of active queries: count candidates in the
 //      query's box (deviceCode.cu:74) and those other than the query itself (:103).
 //   5. queries with >= k others are finished at this level (deviceCode.cu:118): SELECT pass,
@@ -22,9 +22,10 @@
 //      broadcast to the team and every lane decides locally whether it keeps, takes the key, or
 //      takes its left neighbour's entry (DPP row shift).  Rows are written straight from the
 //      team: lane j stores neighbour j (coalesced 4*k bytes per array).
-// Results are bit-identical to the other kernels: same thresholds, same distance arithmetic, keys
-// ordered by (dist, index).
-#include "knn_thresholds.h"
+// Results are bit-identical to the other kernels: the candidate test is the literal one wherever a
+// cheap bound cannot decide it (see the record layout below), same distance arithmetic, keys ordered
+// by (dist, index).
+#include "knn_thresholds.h"  // knn_gate_from_worst
 #include "trueknn_engine.h"
 
 #include <algorithm>
@@ -50,7 +51,7 @@ constexpr int kMaxBlocks = 256;     // leaf blocks one packet may need per level
 #endif
 constexpr int kMaxPerQuery = TKNN_MAX_PER_QUERY;  // leaf blocks one query may need per level
 constexpr int kTeamStack = 192;     // wide-pyramid stack entries per wave
-constexpr int kQrecStride = 12;     // floats per LDS query record (layout below)
+constexpr int kQrecStride = 8;      // floats per LDS query record (layout below)
 constexpr int kMaxStep = 2;          // radius levels one gather may serve (the count slots and the inner-box test assume <= 2)
 // LDS per wave: query records | block list | per-query block lists | counts, query list / stack.
 // The pyramid stack is live only during the gather, the counts and the query list only during the
@@ -64,11 +65,16 @@ constexpr int kLdsStack = kTeamStack * 4;
 constexpr int kLdsShared = (kLdsCnt + kLdsList) > kLdsStack ? (kLdsCnt + kLdsList) : kLdsStack;
 constexpr int kTeamLds = kLdsQrec + kLdsBlk + kLdsMask + kLdsShared;
 
-// LDS query record: [0..2] q, [3] id, [4..9] thresholds of the box the pass works in (outermost
-// level of the step for COUNT, the finishing level for SELECT), [10] row, [11] packed: #blocks |
-// position of the query's own block in its list << 8.  The inner box of a two-level COUNT step is
-// tested literally (deviceCode.cu:38-56 as written) from the query and the inner radius instead of
-// through stored thresholds: 6 more instructions per block in that pass, 1.5 KB less LDS per wave.
+// LDS query record: [0..2] q, [3] id, [4] radius of the box the pass works in (outermost level of
+// the step for COUNT, the finishing level for SELECT), [5] margin of the fast box test, [6] row,
+// [7] packed: #blocks | position of the query's own block in its list << 8.
+//
+// The candidate test (deviceCode.cu:38-56: fl(c-r) <= q <= fl(c+r) per axis) is done in two tiers.
+// With t = max |fl(c_a - q_a)| over the axes (the differences the distance needs anyway) and the
+// margin M = 2^-21 (max_a |q_a| + 2r):  t <= r - M proves the literal test true, t > r + M (or t
+// NaN) proves it false -- the rounding of fl(c-r), fl(c+r) and fl(c-q) is below 2^-23 (|q| + 2r),
+// an eighth of M -- and only candidates inside that 2M band (about 1e-4 of them) run the literal
+// test.  Three instructions instead of stored per-axis thresholds, and 2.5 KB less LDS per wave.
 struct TeamArgs {
   LbvhView bvh, halo;
   LbvhWideView wide[2];
@@ -137,13 +143,6 @@ __device__ __forceinline__ uint32_t t_team_shr1(uint32_t v, uint32_t fill) {
   return (uint32_t)__builtin_amdgcn_update_dpp((int)fill, (int)v, 0x111 /*row_shr:1*/, 0xf, 0xf, false);
 }
 
-// closed-box test lo <= p <= hi on all three axes; requires lo <= hi.  NaN in p gives false.
-__device__ __forceinline__ bool t_in_box(float px, float py, float pz, float lx, float ly, float lz, float hx, float hy,
-                                         float hz) {
-  return (__builtin_amdgcn_fmed3f(px, lx, hx) == px) & (__builtin_amdgcn_fmed3f(py, ly, hy) == py) &
-         (__builtin_amdgcn_fmed3f(pz, lz, hz) == pz);
-}
-
 // acc + (flag ? 1 : 0) as ONE add-with-carry on the compare mask (the compiler's select + add is two)
 __device__ __forceinline__ uint32_t t_count(uint32_t acc, bool flag) {
   const unsigned long long mask = __ballot(flag);
@@ -152,14 +151,13 @@ __device__ __forceinline__ uint32_t t_count(uint32_t acc, bool flag) {
   return out;
 }
 
-// squared distance, knn_dist2's expression ((x*x) + (y*y)) + (z*z) with x and y in one packed lane pair
+// squared distance from the three differences: knn_dist2's expression ((x*x) + (y*y)) + (z*z),
+// x and y squared in one packed instruction
 typedef float t_float2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ float t_dist2(float px, float py, float pz, float qx, float qy, float qz) {
+__device__ __forceinline__ float t_dist2(float dx, float dy, float dz) {
 #pragma clang fp contract(off)
-  const t_float2 pxy = {px, py}, qxy = {qx, qy};
-  const t_float2 dxy = pxy - qxy;
+  const t_float2 dxy = {dx, dy};
   const t_float2 sq = dxy * dxy;
-  const float dz = pz - qz;
   return (sq.x + sq.y) + (dz * dz);
 }
 
@@ -194,9 +192,11 @@ __device__ __forceinline__ void team_pass(const TeamArgs &a, const TeamLds &L, i
     const float *rec = L.qrec + qi * kQrecStride;
     const float t_qx = rec[0], t_qy = rec[1], t_qz = rec[2];
     const int32_t t_qid = __float_as_int(rec[3]);
-    const float t_lx = rec[4], t_ly = rec[5], t_lz = rec[6], t_hx = rec[7], t_hy = rec[8], t_hz = rec[9];
+    const float t_r = rec[4], t_mg = rec[5];
+    const float in_below = t_r - t_mg, in_upto = t_r + t_mg;          // certainly / possibly a candidate
+    const float i0_below = r_inner - t_mg, i0_upto = r_inner + t_mg;  // same for the inner level of a two-level COUNT step
     uint32_t cnt_i0 = 0;  // inner level of a two-level COUNT step (m = levels served by this gather, wave-uniform)
-    const int packed = __float_as_int(rec[11]);
+    const int packed = __float_as_int(rec[7]);
     const int my_n = on ? (packed & 0xff) : 0;  // leaf blocks of my team's query
     int steps = my_n;                                   // wave-uniform trip count: longest list of the 4 teams
     steps = max(steps, (int)__builtin_amdgcn_readlane(my_n, 16));
@@ -241,14 +241,22 @@ __device__ __forceinline__ void team_pass(const TeamArgs &a, const TeamLds &L, i
     float tau2 = INFINITY;
     // one block's test; `it` is wave-uniform
     auto process = [&](const LbvhPoint &p) {
-      // lo <= p <= hi per axis as "the median of (p, lo, hi) is p" (lo <= hi: a query lies in its own
-      // box): one v_med3 + one compare per axis; NaN (sentinels, list overrun) never compares equal
-      const bool in = t_in_box(p.x, p.y, p.z, t_lx, t_ly, t_lz, t_hx, t_hy, t_hz);
+      const float dx = p.x - t_qx, dy = p.y - t_qy, dz = p.z - t_qz;
+      // NaN only if all three are (sentinels; lbvh.hip turns a point with any NaN coordinate into one)
+      const float t = fmaxf(fmaxf(fabsf(dx), fabsf(dy)), fabsf(dz));
+      bool in = t <= in_below;
+      const bool maybe = !in && (t <= in_upto);
+      if (__ballot(maybe) != 0ull) in = in || (maybe && knn_in_box(p.x, p.y, p.z, t_r, t_qx, t_qy, t_qz));
       const bool is_self = in && (p.id == t_qid);  // ids are unique and a query lies in its own box
       cnt = t_count(cnt, in);
-      if (!SELECT && m > 1) cnt_i0 = t_count(cnt_i0, knn_in_box(p.x, p.y, p.z, r_inner, t_qx, t_qy, t_qz));
+      if (!SELECT && m > 1) {
+        bool in0 = t <= i0_below;
+        const bool maybe0 = !in0 && (t <= i0_upto);
+        if (__ballot(maybe0) != 0ull) in0 = in0 || (maybe0 && knn_in_box(p.x, p.y, p.z, r_inner, t_qx, t_qy, t_qz));
+        cnt_i0 = t_count(cnt_i0, in0);
+      }
       if (SELECT) {
-        const float d2 = t_dist2(p.x, p.y, p.z, t_qx, t_qy, t_qz);
+        const float d2 = t_dist2(dx, dy, dz);
         bool pend = in && !is_self && (d2 <= tau2);
         if (TKNN_DIAG_BUILD && (a.diag & 1)) pend = false;
         unsigned long long pm = __ballot(pend);
@@ -325,7 +333,7 @@ __device__ __forceinline__ void team_pass(const TeamArgs &a, const TeamLds &L, i
       // finished at this level (deviceCode.cu:118: k insertions happened): lane j < k stores neighbour j.
       // The query's own lane adds the intersection count and the level afterwards (team_kernel).
       if (on && others >= (uint32_t)a.k && tl < a.k) {
-        const int32_t out_row = __float_as_int(rec[10]);
+        const int32_t out_row = __float_as_int(rec[6]);
         const int64_t o = (int64_t)out_row * a.k + tl;
         const uint64_t key = ((uint64_t)best_d << 32) | best_i;
         const int32_t prim = knn_key_prim(key);
@@ -409,27 +417,26 @@ __global__ void __launch_bounds__(kTeamBlock) __attribute__((amdgpu_waves_per_eu
       const float r_in0 = r;                        // radius of the inner level of a two-level step
       float r_out = r;
       for (int j = 1; j < m; j++) r_out = r_out * 2.0f;
+      // conservative query boxes for the gather: every literal candidate of q at r_out lies inside
       float lo_x = INFINITY, lo_y = INFINITY, lo_z = INFINITY, hi_x = -INFINITY, hi_y = -INFINITY, hi_z = -INFINITY;
       {
-        float *rec = qrec + lane * kQrecStride;
+        const float mg = (fmaxf(fmaxf(fabsf(q.x), fabsf(q.y)), fabsf(q.z)) + 2.0f * r_out) * 4.76837158203125e-07f;  // 2^-21
         if (active) {
-          lo_x = thr_lo(q.x, r_out);
-          lo_y = thr_lo(q.y, r_out);
-          lo_z = thr_lo(q.z, r_out);
-          hi_x = thr_hi(q.x, r_out);
-          hi_y = thr_hi(q.y, r_out);
-          hi_z = thr_hi(q.z, r_out);
+          lo_x = (q.x - r_out) - 2.0f * mg;
+          lo_y = (q.y - r_out) - 2.0f * mg;
+          lo_z = (q.z - r_out) - 2.0f * mg;
+          hi_x = (q.x + r_out) + 2.0f * mg;
+          hi_y = (q.y + r_out) + 2.0f * mg;
+          hi_z = (q.z + r_out) + 2.0f * mg;
         }
+        float *rec = qrec + lane * kQrecStride;
         rec[0] = q.x;
         rec[1] = q.y;
         rec[2] = q.z;
         rec[3] = __int_as_float(q.id);
-        rec[4] = lo_x;
-        rec[5] = lo_y;
-        rec[6] = lo_z;
-        rec[7] = hi_x;
-        rec[8] = hi_y;
-        rec[9] = hi_z;
+        rec[4] = r_out;
+        rec[5] = mg;
+        rec[6] = __int_as_float(row);
       }
       const float g_lo_x = t_wave_min(lo_x), g_lo_y = t_wave_min(lo_y), g_lo_z = t_wave_min(lo_z);
       const float g_hi_x = t_wave_max(hi_x), g_hi_y = t_wave_max(hi_y), g_hi_z = t_wave_max(hi_z);
@@ -543,8 +550,8 @@ __global__ void __launch_bounds__(kTeamBlock) __attribute__((amdgpu_waves_per_eu
         active = false;
         break;
       }
-      int my_packed = my_nblk | (my_own_pos << 8);  // read back by the teams; the level is added below
-      qrec[lane * kQrecStride + 11] = __int_as_float(my_packed);
+      const int my_packed = my_nblk | (my_own_pos << 8);  // read back by the teams
+      qrec[lane * kQrecStride + 7] = __int_as_float(my_packed);
 
       PHASE_END(1);
       // ---- 4. passes ---------------------------------------------------------------------------
@@ -554,7 +561,6 @@ __global__ void __launch_bounds__(kTeamBlock) __attribute__((amdgpu_waves_per_eu
       // count all m nested boxes in one pass, pick the first level with >= k others, select there.
       // A row is written only when its query really has >= k others in the chosen box, so neither
       // speculation nor level grouping can change a result.
-      qrec[lane * kQrecStride + 10] = __int_as_float(row);
       const bool speculate = m == 1 && active && level > 0 && prev_others * 8u >= (uint32_t)(a.k + a.k / 2);
       const bool count_first = active && !speculate;
       {
@@ -579,16 +585,7 @@ __global__ void __launch_bounds__(kTeamBlock) __attribute__((amdgpu_waves_per_eu
           fin_at = 1;
       }
       const bool select_now = speculate || fin_at >= 0;
-      if (m > 1 && fin_at == 0) {
-        // finishing inside the step: the SELECT pass works in that inner box
-        float *rec = qrec + lane * kQrecStride;
-        rec[4] = thr_lo(q.x, r_in0);
-        rec[5] = thr_lo(q.y, r_in0);
-        rec[6] = thr_lo(q.z, r_in0);
-        rec[7] = thr_hi(q.x, r_in0);
-        rec[8] = thr_hi(q.y, r_in0);
-        rec[9] = thr_hi(q.z, r_in0);
-      }
+      if (m > 1 && fin_at == 0) qrec[lane * kQrecStride + 4] = r_in0;  // finishing inside the step: SELECT works in the inner box
       {
         const unsigned long long sm = __ballot(select_now);
         t_wave_sync();
