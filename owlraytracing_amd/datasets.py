@@ -150,3 +150,34 @@ def write_csv_points(path, points):
     with open(path, "w") as fh:
         for row in pts:
             fh.write(",".join(repr(float(v)) for v in row) + "\n")
+
+
+def boundary_band(anchors: int, r0: float, seed: int = 0, levels: int = 3, spread: float = 600.0) -> np.ndarray:
+    """Points that sit ON the candidate-box faces of other points, a few ulps either side.
+
+    Around each of ``anchors`` points (coordinates up to +-``spread``, i.e. far larger than r0) every
+    axis, sign and level j < ``levels`` gets satellites at distance r0*2^j, nudged by -2..+2 ulps
+    along that axis; the other two coordinates stay well inside the box.  Whether such a point is a
+    candidate depends on the rounding of fl(c - r) and fl(c + r) (deviceCode.cu:38-56), which is
+    what tests of the box-test arithmetic want to see exercised at every magnitude.
+    """
+    rng = np.random.default_rng(seed)
+    mags = np.array([1e-3, 0.07, 1.0, 37.5, spread], dtype=np.float64)
+    out = []
+    for a in range(anchors):
+        c = ((rng.random(3) * 2 - 1) * mags[a % len(mags)]).astype(np.float32)
+        out.append(c)
+        for j in range(levels):
+            r = np.float32(r0) * np.float32(2.0 ** j)
+            for ax in range(3):
+                for sign in (-1.0, 1.0):
+                    for nudge in range(-2, 3):
+                        p = c + ((rng.random(3) - 0.5) * float(r0) * 0.5).astype(np.float32)
+                        v = np.float32(c[ax] + np.float32(sign) * r)
+                        step = np.float32(np.inf if nudge > 0 else -np.inf)
+                        for _ in range(abs(nudge)):
+                            v = np.nextafter(v, step)
+                        p[ax] = v
+                        out.append(p)
+    pts = np.asarray(out, dtype=np.float32)
+    return pts[rng.permutation(len(pts))]

@@ -46,6 +46,8 @@ def cases():
     yield "minimal_n6_k5", datasets.uniform3d(6, seed=10), 5, 0.05
     yield "taxi2d_n3000_k7", datasets.pad_to_3d(datasets.taxi_like2d(3000, components=16, seed=2)), 7, 0.001
     yield "k32_n2500", datasets.uniform3d(2500, seed=11), 32, 0.03
+    # satellites on the box faces of 40 anchors, +-2 ulps, coordinates from 1e-3 to 600
+    yield "boundaryband_n3640_k7", datasets.boundary_band(40, 0.01, seed=4), 7, 0.01
 
 
 def main():

@@ -93,6 +93,47 @@ def test_planar_input_and_heavy_tail(kernel):
     eng.close()
 
 
+@pytest.mark.parametrize("kernel", KERNELS, ids=KERNEL_IDS)
+def test_points_on_box_faces_at_every_magnitude(kernel):
+    """Satellites +-2 ulps around the box faces fl(c -+ r) of 400 anchors with coordinates from 1e-3
+    to 600: the cases where bounds on |c - q| cannot decide the candidate test (team kernel's
+    literal fallback) and where the exact thresholds of the lane/wave kernels sit."""
+    xyz = datasets.boundary_band(400, 0.01, seed=11)
+    ref = oracle.trueknn(xyz, 7, 0.01)
+    eng = _engine()
+    eng.build(xyz)
+    r = eng.solve(7, 0.01, kernel=kernel)
+    assert r["info"]["rounds"] == ref["rounds"]
+    assert np.array_equal(r["intersections"].cpu().numpy(), ref["intersections"])
+    assert np.array_equal(r["idx"].cpu().numpy(), ref["idx"])
+    assert np.array_equal(r["dist"].cpu().numpy().view(np.int32), ref["dist"].view(np.int32))
+    eng.close()
+
+
+@pytest.mark.parametrize("kernel", KERNELS, ids=KERNEL_IDS)
+def test_points_with_nan_coordinates_are_nobodys_candidates(kernel):
+    """A NaN coordinate fails every closed-box comparison (deviceCode.cu:38-56 on IEEE floats), so
+    such a point is never a candidate; as a query it never finishes (allow_unfinished reports it)."""
+    xyz = datasets.uniform3d(20_000, seed=21)
+    bad = np.array([5, 777, 19_999])
+    xyz[bad[0], 0] = np.nan
+    xyz[bad[1], 1] = np.nan
+    xyz[bad[2]] = np.nan
+    good = np.setdiff1d(np.arange(len(xyz)), bad)
+    k, r0 = 5, datasets.start_radius(len(xyz), 5)
+    ref = oracle.trueknn(xyz[good], k, r0)
+    eng = _engine()
+    eng.build(xyz)
+    r = eng.solve(k, r0, kernel=kernel, max_rounds=ref["rounds"] + 2, allow_unfinished=True)
+    assert r["info"]["unfinished"] == len(bad)
+    idx = r["idx"].cpu().numpy()[good]
+    assert not np.isin(idx, bad).any()
+    assert np.array_equal(idx, good[ref["idx"]])
+    assert np.array_equal(r["dist"].cpu().numpy()[good].view(np.int32), ref["dist"].view(np.int32))
+    assert np.array_equal(r["intersections"].cpu().numpy()[good], ref["intersections"])
+    eng.close()
+
+
 def test_candidate_thresholds_equal_the_literal_box_test():
     """lo <= c <= hi must select exactly the c with fl(c - r) <= q <= fl(c + r), including near
     zero, across binades and at exact box boundaries (where a per-ulp walk would take forever)."""
