@@ -214,26 +214,33 @@ __device__ __forceinline__ void team_pass(const TeamArgs &a, const TeamLds &L, i
     // my list" check
     const int32_t nan_block = a.wide[0].count[0];
     int32_t e0 = nan_block, e1 = nan_block, e2 = nan_block, e3 = nan_block, e4 = nan_block, e5 = nan_block;  // named, not an array: must stay in VGPRs
-    // Blocks are visited outward from the query's own block, alternating sides of its Morton-ordered
+    // SELECT visits blocks outward from the query's own block, alternating sides of its Morton-ordered
     // list: near blocks first tightens the k-th-distance gate early (about 30 % fewer inserts than
     // list order on uniform data) and changes nothing else -- the result does not depend on order.
-    const int own_pos = on ? ((packed >> 8) & 0xff) : 0;
-    const int left = own_pos, right = last - own_pos, both = min(left, right);
+    // COUNT takes the list as it is.  Branch-free: registers are filled by whole-wave decisions
+    // (`steps`), lanes past their list's end read some byte of their row and drop it.
+    const int own_pos = (packed >> 8) & 0xff;
+    const int both = min(own_pos, last - own_pos);
+    const bool right_longer = last - own_pos > own_pos;
     auto list_pos = [&](int it) -> int {
-      if (it == 0) return own_pos;
-      if (it <= 2 * both) return (it & 1) ? own_pos + ((it + 1) >> 1) : own_pos - (it >> 1);
+      if (!SELECT) return it;
+      const int half = (it + 1) >> 1;
+      const int alt = (it & 1) ? half : -half;  // it = 0: own block
       const int far = it - both;
-      return right > left ? own_pos + far : own_pos - far;
+      const int off = it <= 2 * both ? alt : (right_longer ? far : -far);
+      return own_pos + off;
     };
-    auto list_entry = [&](int pos) -> int32_t { return pos <= last ? L.blk[mine[list_pos(pos)]] : nan_block; };
-    if (my_n > 0) {
-      e0 = list_entry(tl);
-      if (last >= 16) e1 = list_entry(tl + 16);
-      if (last >= 32) e2 = list_entry(tl + 32);
-      if (last >= 48) e3 = list_entry(tl + 48);
-      if (last >= 64) e4 = list_entry(tl + 64);
-      if (last >= 80) e5 = list_entry(tl + 80);
-    }
+    auto list_entry = [&](int pos) -> int32_t {
+      const int at = min(max(list_pos(pos), 0), kMaxPerQuery - 1);
+      const int32_t e = L.blk[mine[at]];
+      return pos <= last ? e : nan_block;
+    };
+    e0 = list_entry(tl);
+    if (steps > 16) e1 = list_entry(tl + 16);
+    if (steps > 32) e2 = list_entry(tl + 32);
+    if (steps > 48) e3 = list_entry(tl + 48);
+    if (steps > 64) e4 = list_entry(tl + 64);
+    if (steps > 80) e5 = list_entry(tl + 80);
     auto entry_reg = [&](int j) -> int32_t {  // j is wave-uniform
       return j == 0 ? e0 : (j == 1 ? e1 : (j == 2 ? e2 : (j == 3 ? e3 : (j == 4 ? e4 : e5))));
     };
