@@ -225,7 +225,7 @@ Engine::Engine() {
   OWLMI_HIP(hipGetDevice(&device_));
   OWLMI_HIP(hipEventCreate(&ev_a_));
   OWLMI_HIP(hipEventCreate(&ev_b_));
-  OWLMI_HIP(hipMalloc((void **)&counters_, 16 * sizeof(unsigned long long)));
+  OWLMI_HIP(hipMalloc((void **)&counters_, 32 * sizeof(unsigned long long)));  // [16..23]: the team kernel's per-XCD packet counters
   OWLMI_HIP(hipHostMalloc((void **)&h_counters_, 16 * sizeof(unsigned long long)));
   if (const char *e = getenv("TKNN_LEAF_MAX")) {
     int v = atoi(e);
