@@ -56,6 +56,7 @@ struct LbvhView {
   const int32_t *prim_id;   /* n: caller's primitive index of sorted slot */
   int32_t n;
   int32_t root; /* 0, or ~0 when n == 1 */
+  const int32_t *nan_count; /* device: how many of the LAST sorted points have a NaN coordinate (point sets) */
 };
 
 #if defined(__HIPCC__)

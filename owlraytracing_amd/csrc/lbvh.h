@@ -48,6 +48,8 @@ class Lbvh {
   LbvhView view() const;
   LbvhWideView wide_view() const;  // point trees only
   const float *scene_device() const { return scene_; }  // 6 floats: lo xyz, hi xyz of the built set
+  // device counter behind the scene box: points with a NaN coordinate (they sort last)
+  int32_t *nan_count() const { return reinterpret_cast<int32_t *>(scene_ + 6); }
   int64_t size() const { return n_; }
   bool built() const { return built_; }
   bool has_points() const { return points_ != nullptr && point_mode_; }

@@ -134,7 +134,11 @@ __global__ void __launch_bounds__(kBlock) morton_kernel(const float *__restrict_
     t = fminf(fmaxf(t, 0.f), 2097151.0f);  // NaN -> 0 via fmaxf
     q[a] = (uint64_t)t;
   }
-  codes[i] = (spread21(q[0]) << 2) | (spread21(q[1]) << 1) | spread21(q[2]);
+  uint64_t code = (spread21(q[0]) << 2) | (spread21(q[1]) << 1) | spread21(q[2]);
+  // a primitive with a NaN coordinate sorts after every real one (bit 63): such points are nobody's
+  // candidates, and kernels that add up whole subtrees need to know where they are
+  if (c[0] != c[0] || c[1] != c[1] || c[2] != c[2]) code = 1ull << 63;
+  codes[i] = code;
   order[i] = (uint32_t)i;
 }
 
@@ -145,7 +149,8 @@ __global__ void __launch_bounds__(kBlock) gather_kernel(const float *__restrict_
                                                        LbvhPoint *__restrict__ points,
                                                        LbvhBox *__restrict__ sorted_boxes,
                                                        int32_t *__restrict__ prim_id,
-                                                       const int32_t *__restrict__ ids) {
+                                                       const int32_t *__restrict__ ids,
+                                                       int32_t *__restrict__ nan_count) {
   int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   if (i >= n) {
     // sentinels fill the last leaf block and one whole block after it (the team kernel's "no
@@ -167,7 +172,11 @@ __global__ void __launch_bounds__(kBlock) gather_kernel(const float *__restrict_
     p.z = xyz[3 * (int64_t)src + 2];
     // a point with any NaN coordinate is nobody's candidate (every closed-box comparison with NaN is
     // false) and finds none; store it as all-NaN so that kernels may test |c - q| per axis first
-    if (p.x != p.x || p.y != p.y || p.z != p.z) p.x = p.y = p.z = __uint_as_float(0x7fc00000u);
+    // (morton_kernel sorts them last: they are the last *nan_count points of the sorted order)
+    if (p.x != p.x || p.y != p.y || p.z != p.z) {
+      p.x = p.y = p.z = __uint_as_float(0x7fc00000u);
+      atomicAdd(nan_count, 1);
+    }
     p.id = ids ? ids[src] : (int32_t)src;
     points[i] = p;
   } else {
@@ -373,7 +382,7 @@ void Lbvh::reserve(int64_t n) {
   dev_alloc(order_alt_, (size_t)n, total);
   sort_tmp_bytes_ = 0;
   OWLMI_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, sort_tmp_bytes_, codes_, codes_alt_, order_,
-                                              order_alt_, (int)n, 0, 63, (hipStream_t)0));
+                                              order_alt_, (int)n, 0, 64, (hipStream_t)0));
   OWLMI_HIP(hipMalloc(&sort_tmp_, sort_tmp_bytes_ ? sort_tmp_bytes_ : 16));
   total += sort_tmp_bytes_;
   dev_alloc(nodes_, (size_t)(n > 1 ? n - 1 : 1), total);
@@ -426,7 +435,7 @@ LbvhWideView Lbvh::wide_view() const {
 
 void Lbvh::sort_and_tree(hipStream_t stream) {
   OWLMI_HIP(hipcub::DeviceRadixSort::SortPairs(sort_tmp_, sort_tmp_bytes_, codes_, codes_alt_, order_,
-                                              order_alt_, (int)n_, 0, 63, stream));
+                                              order_alt_, (int)n_, 0, 64, stream));
   if (n_ > 1) {
     hipLaunchKernelGGL(karras_kernel, dim3(blocks_for(n_ - 1)), dim3(kBlock), 0, stream, codes_alt_, n_,
                        nodes_, split_owner_);
@@ -474,9 +483,10 @@ void Lbvh::build_from_points(const float *d_xyz, int64_t n, hipStream_t stream, 
   hipLaunchKernelGGL(morton_kernel<true>, dim3(blocks_for(n)), dim3(kBlock), 0, stream, d_xyz,
                      (const LbvhBox *)nullptr, n, scene_, codes_, order_);
   OWLMI_HIP(hipGetLastError());
+  OWLMI_HIP(hipMemsetAsync(nan_count(), 0, sizeof(int32_t), stream));
   sort_and_tree(stream);
   hipLaunchKernelGGL(gather_kernel<true>, dim3(blocks_for(n + 2 * LBVH_BLOCK)), dim3(kBlock), 0, stream, d_xyz,
-                     (const LbvhBox *)nullptr, n, order_alt_, points_, (LbvhBox *)nullptr, prim_id_, d_ids);
+                     (const LbvhBox *)nullptr, n, order_alt_, points_, (LbvhBox *)nullptr, prim_id_, d_ids, nan_count());
   OWLMI_HIP(hipGetLastError());
   fit(stream);
   build_wide(stream);
@@ -495,9 +505,10 @@ void Lbvh::build_from_boxes(const LbvhBox *d_boxes, int64_t n, hipStream_t strea
   hipLaunchKernelGGL(morton_kernel<false>, dim3(blocks_for(n)), dim3(kBlock), 0, stream,
                      (const float *)nullptr, d_boxes, n, scene_, codes_, order_);
   OWLMI_HIP(hipGetLastError());
+  OWLMI_HIP(hipMemsetAsync(nan_count(), 0, sizeof(int32_t), stream));
   sort_and_tree(stream);
   hipLaunchKernelGGL(gather_kernel<false>, dim3(blocks_for(n)), dim3(kBlock), 0, stream,
-                     (const float *)nullptr, d_boxes, n, order_alt_, (LbvhPoint *)nullptr, boxes_, prim_id_, (const int32_t *)nullptr);
+                     (const float *)nullptr, d_boxes, n, order_alt_, (LbvhPoint *)nullptr, boxes_, prim_id_, (const int32_t *)nullptr, nan_count());
   OWLMI_HIP(hipGetLastError());
   fit(stream);
   built_ = true;
@@ -506,7 +517,7 @@ void Lbvh::build_from_boxes(const LbvhBox *d_boxes, int64_t n, hipStream_t strea
 void Lbvh::refit_boxes(const LbvhBox *d_boxes, hipStream_t stream) {
   if (!built_ || point_mode_) throw HipError{"Lbvh::refit_boxes: no box tree to refit"};
   hipLaunchKernelGGL(gather_kernel<false>, dim3(blocks_for(n_)), dim3(kBlock), 0, stream,
-                     (const float *)nullptr, d_boxes, n_, order_alt_, (LbvhPoint *)nullptr, boxes_, prim_id_, (const int32_t *)nullptr);
+                     (const float *)nullptr, d_boxes, n_, order_alt_, (LbvhPoint *)nullptr, boxes_, prim_id_, (const int32_t *)nullptr, nan_count());
   OWLMI_HIP(hipGetLastError());
   fit(stream);
 }
@@ -521,6 +532,7 @@ LbvhView Lbvh::view() const {
   v.prim_id = prim_id_;
   v.n = (int32_t)n_;
   v.root = n_ > 1 ? 0 : ~0;
+  v.nan_count = nan_count();
   return v;
 }
 

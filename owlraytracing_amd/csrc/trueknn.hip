@@ -7,6 +7,7 @@
 //   owl_device.h:150-174   optixTrace (RT cores)       -> rope traversal of the LBVH
 //   deviceCode.cu:62-138   __intersection__Spheres     -> box test + register k-list insert
 //   hostCode.cpp:285-340   round loop                  -> Engine::solve_lane
+#include "knn_thresholds.h"  // knn_gate_from_worst
 #include "trueknn_engine.h"
 
 #include <algorithm>
@@ -19,6 +20,7 @@ namespace owlmi {
 namespace {
 
 constexpr int kLaneBlock = 256;
+constexpr int kCountedSubtree = 32;  // smallest subtree the lane kernel tries to count instead of walking
 
 struct LaneRoundArgs {
   LbvhView bvh;
@@ -34,7 +36,7 @@ struct LaneRoundArgs {
   float *out_dist;         // n*k (may be null)
   int64_t *out_isect;      // n (may be null)
   tknnNeigh *out_fb;       // n*k (may be null)
-  unsigned long long *counters;  // [0] unfinished, [1] node tests, [2] point tests, [3] sum isect, [4] active lanes
+  unsigned long long *counters;  // [0] unfinished, [1] node tests, [2] point tests, [3] sum isect, [4] active lanes, [5], [6] candidates of the active lanes, plain and squared
 };
 
 template <int K>
@@ -66,7 +68,10 @@ __device__ __forceinline__ void write_row(const LaneRoundArgs &a, int32_t row, c
   if (a.out_level) a.out_level[row] = a.level;
 }
 
-template <int K>
+// SUBTREES: count fully covered subtrees beyond the gate instead of walking them (see below).  In a
+// wave some lane is at a large node most of the time, so the test is paid on most steps: launches
+// whose boxes hold few points run without it (Engine::lane_rounds decides per round).
+template <int K, bool SUBTREES>
 __global__ void __launch_bounds__(kLaneBlock) lane_round_kernel(LaneRoundArgs a) {
   const int32_t t = blockIdx.x * kLaneBlock + threadIdx.x;
   const LbvhView &bvh = a.bvh;
@@ -80,9 +85,11 @@ __global__ void __launch_bounds__(kLaneBlock) lane_round_kernel(LaneRoundArgs a)
   list.clear();
   int32_t cnt = 0, others = 0;
   uint32_t node_tests = 0, point_tests = 0;
+  float tau2 = INFINITY;  // squared-distance gate from the list's last entry: beyond it nothing enters
   for (int tree = 0; tree < 2; tree++) {
     const LbvhView &tv = tree == 0 ? a.bvh : a.halo;
     if (tv.n <= 0) continue;
+    const int32_t clean_end = tv.n - (tv.nan_count ? *tv.nan_count : 0);  // NaN points sort last
     int32_t ref = active ? tv.root : LBVH_END;
     while (ref != LBVH_END) {
       if (ref >= 0) {
@@ -92,6 +99,31 @@ __global__ void __launch_bounds__(kLaneBlock) lane_round_kernel(LaneRoundArgs a)
         // so fl(c_p - r) >= fl(lo - r) and fl(c_p + r) <= fl(hi + r)
         bool hit = (nd.lo[0] - r <= q.x) & (q.x <= nd.hi[0] + r) & (nd.lo[1] - r <= q.y) &
                    (q.y <= nd.hi[1] + r) & (nd.lo[2] - r <= q.z) & (q.z <= nd.hi[2] + r);
+        // The same monotonicity the other way round: if even the largest centre passes the lower
+        // test and the smallest the upper one, EVERY point of the node is a candidate
+        // (deviceCode.cu:74 would count each).  If, besides, none of them can enter the list any
+        // more -- the node lies beyond the gate -- the subtree is counted, not walked: a query
+        // whose box has grown over a whole cluster costs O(log n) instead of O(cluster).
+        // Only tried for subtrees of at least kCountedSubtree points: near the leaves the test would
+        // cost as much as the node test itself and save nothing.
+        const int32_t first = lbvh_first(ref, nd.other), last = lbvh_last(ref, nd.other);
+        const bool inside = SUBTREES && hit && last - first + 1 >= kCountedSubtree && (nd.hi[0] - r <= q.x) & (q.x <= nd.lo[0] + r) &
+                                       (nd.hi[1] - r <= q.y) & (q.y <= nd.lo[1] + r) & (nd.hi[2] - r <= q.z) & (q.z <= nd.lo[2] + r);
+        if (inside) {
+          const float gx = fmaxf(fmaxf(nd.lo[0] - q.x, q.x - nd.hi[0]), 0.f);
+          const float gy = fmaxf(fmaxf(nd.lo[1] - q.y, q.y - nd.hi[1]), 0.f);
+          const float gz = fmaxf(fmaxf(nd.lo[2] - q.z, q.z - nd.hi[2]), 0.f);
+          const float m2 = (gx * gx + gy * gy) + gz * gz;  // <= every point's squared distance, up to rounding
+          // 5e-6 covers the roundings of m2 and of the points' own distance arithmetic; a node that
+          // holds the query itself has m2 = 0 and is never skipped, so `others` stays right
+          if (m2 * 0.999995f > tau2 && last < clean_end) {
+            const int32_t c = last - first + 1;
+            cnt += c;
+            others += c;
+            ref = tv.rope_node[ref];
+            continue;
+          }
+        }
         ref = hit ? lbvh_left_ref(ref, nd) : tv.rope_node[ref];
       } else {
         const int32_t slot = ~ref;
@@ -103,6 +135,7 @@ __global__ void __launch_bounds__(kLaneBlock) lane_round_kernel(LaneRoundArgs a)
             others++;
             float d = knn_sqrt(knn_dist2(p.x, p.y, p.z, q.x, q.y, q.z));
             list.insert(knn_key(d, p.id));
+            if (SUBTREES) tau2 = knn_gate_from_worst(knn_key_dist(list.worst()));
           }
         }
         ref = tv.rope_leaf[slot];
@@ -125,25 +158,38 @@ __global__ void __launch_bounds__(kLaneBlock) lane_round_kernel(LaneRoundArgs a)
   unsigned long long unfinished = __popcll(__ballot((active && !finished) || waiting));
   unsigned long long traced = __popcll(__ballot(active));
   unsigned long long nt = node_tests, pt = point_tests, si = finished ? (unsigned long long)isect : 0ull;
+  // candidates of the active lanes, plain and squared (capped): sum c^2 / sum c is the box population
+  // a random candidate TEST of this round saw, the figure that says where the round's work was
+  const unsigned long long cc = active ? (unsigned long long)min(cnt, 65535) : 0ull;
+  unsigned long long sc = cc, sc2 = cc * cc;
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) {
     nt += __shfl_xor(nt, off);
     pt += __shfl_xor(pt, off);
     si += __shfl_xor(si, off);
+    sc += __shfl_xor(sc, off);
+    sc2 += __shfl_xor(sc2, off);
   }
   if ((threadIdx.x & 63) == 0) {
     if (unfinished) atomicAdd(&a.counters[0], unfinished);
-    atomicAdd(&a.counters[1], nt);
-    atomicAdd(&a.counters[2], pt);
+    if (nt) atomicAdd(&a.counters[1], nt);
+    if (pt) atomicAdd(&a.counters[2], pt);
     if (si) atomicAdd(&a.counters[3], si);
     if (traced) atomicAdd(&a.counters[4], traced);
+    if (sc) {
+      atomicAdd(&a.counters[5], sc);
+      atomicAdd(&a.counters[6], sc2);
+    }
   }
 }
 
 template <int K>
-void launch_lane(const LaneRoundArgs &a, hipStream_t s) {
+void launch_lane(const LaneRoundArgs &a, bool subtrees, hipStream_t s) {
   unsigned blocks = (unsigned)((a.bvh.n + kLaneBlock - 1) / kLaneBlock);
-  hipLaunchKernelGGL(lane_round_kernel<K>, dim3(blocks), dim3(kLaneBlock), 0, s, a);
+  if (subtrees)
+    hipLaunchKernelGGL((lane_round_kernel<K, true>), dim3(blocks), dim3(kLaneBlock), 0, s, a);
+  else
+    hipLaunchKernelGGL((lane_round_kernel<K, false>), dim3(blocks), dim3(kLaneBlock), 0, s, a);
 }
 
 // ---- exact-kNN repair (opt-in, never part of tknnSolve) ----------------
@@ -288,6 +334,21 @@ void Engine::build(const float *d_xyz, const int32_t *d_ids, int64_t n, tknnBuil
   }
 }
 
+// points a candidate box of this radius holds at the mean density of the built set (a work estimate)
+double Engine::expected_box_population(float radius) const {
+  double measure = 1.0;
+  int dims = 0;
+  for (int a = 0; a < 3; a++) {
+    const double e = (double)scene_[3 + a] - (double)scene_[a];
+    if (e > 0) {
+      measure *= e;
+      dims++;
+    }
+  }
+  if (dims == 0 || !(measure > 0)) return (double)bvh_.size();
+  return (double)bvh_.size() / measure * std::pow(2.0 * (double)radius, dims);
+}
+
 void Engine::solve_lane(const SolveArgs &sa, tknnSolveInfo *info, hipStream_t s) { lane_rounds(sa, 0, true, info, s); }
 
 void Engine::continue_lane(const SolveArgs &sa, int first_level, tknnSolveInfo *info, hipStream_t s) {
@@ -319,6 +380,9 @@ void Engine::lane_rounds(const SolveArgs &sa, int first_level, bool fresh, tknnS
   float radius = sa.start_radius, total_ms = 0;
   int rounds = first_level, launches = 0;
   for (int t = 0; t < first_level; t++) radius *= 2;
+  double predicted_candidates = expected_box_population(radius);
+  const double growth = expected_box_population(2.0f) / std::max(expected_box_population(1.0f), 1e-300);  // 2^dims
+  unsigned long long c1_before = 0, c2_before = 0;
   for (;;) {
     if (rounds >= sa.max_rounds) {
       if (sa.allow_unfinished) break;
@@ -328,30 +392,42 @@ void Engine::lane_rounds(const SolveArgs &sa, int first_level, bool fresh, tknnS
     rounds++;
     launches++;
     a.radius = radius;
+    // Subtree counting pays when boxes hold hundreds of points.  Stragglers handed over by the team
+    // kernel are exactly those queries; otherwise predict from the round before -- the population of
+    // the box an average candidate test worked in, times 2^dims -- and for the first round from
+    // the scene's mean density.
+    const bool subtrees = !fresh || predicted_candidates >= 256.0;
     OWLMI_HIP(hipMemsetAsync(counters_, 0, sizeof(unsigned long long), s));  // [0] only
     OWLMI_HIP(hipEventRecord(ev_a_, s));
     switch (cap) {
-      case 1: launch_lane<1>(a, s); break;
-      case 2: launch_lane<2>(a, s); break;
-      case 4: launch_lane<4>(a, s); break;
-      case 5: launch_lane<5>(a, s); break;
-      case 8: launch_lane<8>(a, s); break;
-      case 10: launch_lane<10>(a, s); break;
-      case 16: launch_lane<16>(a, s); break;
-      case 24: launch_lane<24>(a, s); break;
-      case 32: launch_lane<32>(a, s); break;
-      default: launch_lane<64>(a, s); break;
+      case 1: launch_lane<1>(a, subtrees, s); break;
+      case 2: launch_lane<2>(a, subtrees, s); break;
+      case 4: launch_lane<4>(a, subtrees, s); break;
+      case 5: launch_lane<5>(a, subtrees, s); break;
+      case 8: launch_lane<8>(a, subtrees, s); break;
+      case 10: launch_lane<10>(a, subtrees, s); break;
+      case 16: launch_lane<16>(a, subtrees, s); break;
+      case 24: launch_lane<24>(a, subtrees, s); break;
+      case 32: launch_lane<32>(a, subtrees, s); break;
+      default: launch_lane<64>(a, subtrees, s); break;
     }
     OWLMI_HIP(hipGetLastError());
     OWLMI_HIP(hipEventRecord(ev_b_, s));
     // hostCode.cpp:310-330: the host decides about another round from the result state
-    OWLMI_HIP(hipMemcpyAsync(h_counters_, counters_, 5 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+    OWLMI_HIP(hipMemcpyAsync(h_counters_, counters_, 7 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
     OWLMI_HIP(hipStreamSynchronize(s));
     float ms = 0;
     OWLMI_HIP(hipEventElapsedTime(&ms, ev_a_, ev_b_));
     total_ms += ms;
     if (h_counters_[0] == 0) break;
     if (rounds >= sa.max_rounds && sa.allow_unfinished) break;
+    {
+      // counters [5], [6] accumulate over rounds: this round's share is the difference
+      const double c1 = (double)(h_counters_[5] - c1_before), c2 = (double)(h_counters_[6] - c2_before);
+      c1_before = h_counters_[5];
+      c2_before = h_counters_[6];
+      predicted_candidates = (c1 > 0 ? c2 / c1 : 0.0) * growth;
+    }
     radius *= 2;  // hostCode.cpp:321 (fp32)
   }
   if (info) {

@@ -45,6 +45,7 @@ class Engine {
   void build(const float *d_xyz, const int32_t *d_ids, int64_t n, tknnBuildInfo *info, hipStream_t s);
   void set_halo(const float *d_xyz, const int32_t *d_ids, int64_t m, hipStream_t s);
   LbvhView halo_view() const;
+  double expected_box_population(float radius) const;
   void solve(const SolveArgs &sa, int kernel, tknnSolveInfo *info, hipStream_t s);
   // rewrites the rows whose k-th distance exceeds their final box half-width with exact kNN; returns how many
   int64_t repair_exact(int k, float start_radius, const int32_t *d_levels, int32_t *d_idx, float *d_dist, hipStream_t s);

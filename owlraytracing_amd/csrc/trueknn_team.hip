@@ -52,6 +52,7 @@ constexpr int kMaxBlocks = 256;     // leaf blocks one packet may need per level
 constexpr int kMaxPerQuery = TKNN_MAX_PER_QUERY;  // leaf blocks one query may need per level
 constexpr int kTeamStack = 192;     // wide-pyramid stack entries per wave
 constexpr int kQrecStride = 8;      // floats per LDS query record (layout below)
+constexpr int kScanBudget = 16384;  // leaf blocks one packet-level may test against its queries before it is handed over
 constexpr int kMaxStep = 2;          // radius levels one gather may serve (the count slots and the inner-box test assume <= 2)
 // LDS per wave: query records | block list | per-query block lists | counts, query list / stack.
 // The pyramid stack is live only during the gather, the counts and the query list only during the
@@ -108,11 +109,6 @@ __device__ __forceinline__ void t_wave_sync() {
 __device__ __forceinline__ float t_bcast(float v, int lane) {
   return __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(v), lane));
 }
-__device__ __forceinline__ float t_wave_min(float v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v = fminf(v, __shfl_xor(v, off));
-  return v;
-}
 __device__ __forceinline__ float t_wave_max(float v) {
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off));
@@ -136,6 +132,21 @@ __device__ __forceinline__ uint32_t t_team_sum(uint32_t v) {
   v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x124 /*row_ror:4*/, 0xf, 0xf, false);
   v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x122 /*row_ror:2*/, 0xf, 0xf, false);
   v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x121 /*row_ror:1*/, 0xf, 0xf, false);
+  return v;
+}
+// min / max over the 16 lanes of my team, result in every lane of the team
+__device__ __forceinline__ float t_team_min(float v) {
+  v = fminf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x128 /*row_ror:8*/, 0xf, 0xf, false)));
+  v = fminf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x124 /*row_ror:4*/, 0xf, 0xf, false)));
+  v = fminf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x122 /*row_ror:2*/, 0xf, 0xf, false)));
+  v = fminf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x121 /*row_ror:1*/, 0xf, 0xf, false)));
+  return v;
+}
+__device__ __forceinline__ float t_team_max(float v) {
+  v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x128 /*row_ror:8*/, 0xf, 0xf, false)));
+  v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x124 /*row_ror:4*/, 0xf, 0xf, false)));
+  v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x122 /*row_ror:2*/, 0xf, 0xf, false)));
+  v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x121 /*row_ror:1*/, 0xf, 0xf, false)));
   return v;
 }
 // my left neighbour's value inside the team (lane 0 of a team gets `fill`)
@@ -464,14 +475,37 @@ __global__ void __launch_bounds__(kTeamBlock) __attribute__((amdgpu_waves_per_eu
         rec[5] = mg;
         rec[6] = __int_as_float(row);
       }
-      const float g_lo_x = t_wave_min(lo_x), g_lo_y = t_wave_min(lo_y), g_lo_z = t_wave_min(lo_z);
-      const float g_hi_x = t_wave_max(hi_x), g_hi_y = t_wave_max(hi_y), g_hi_z = t_wave_max(hi_z);
+      // The pyramid is culled against FOUR boxes, one per 16 Morton-consecutive queries (= one leaf
+      // block of queries), not against the packet's one union box: where the Z-curve jumps, or
+      // among the outliers of a clustered set, the union covers space none of the queries needs.
+      float s_lo_x[4], s_lo_y[4], s_lo_z[4], s_hi_x[4], s_hi_y[4], s_hi_z[4];
+      {
+        const float r_lo_x = t_team_min(lo_x), r_lo_y = t_team_min(lo_y), r_lo_z = t_team_min(lo_z);
+        const float r_hi_x = t_team_max(hi_x), r_hi_y = t_team_max(hi_y), r_hi_z = t_team_max(hi_z);
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          s_lo_x[j] = t_bcast(r_lo_x, 16 * j);
+          s_lo_y[j] = t_bcast(r_lo_y, 16 * j);
+          s_lo_z[j] = t_bcast(r_lo_z, 16 * j);
+          s_hi_x[j] = t_bcast(r_hi_x, 16 * j);
+          s_hi_y[j] = t_bcast(r_hi_y, 16 * j);
+          s_hi_z[j] = t_bcast(r_hi_z, 16 * j);
+        }
+      }
+      auto overlaps_packet = [&](const LbvhBox &bx) -> bool {
+        bool any = false;
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+          any |= (bx.lo[0] <= s_hi_x[j]) & (bx.hi[0] >= s_lo_x[j]) & (bx.lo[1] <= s_hi_y[j]) & (bx.hi[1] >= s_lo_y[j]) &
+                 (bx.lo[2] <= s_hi_z[j]) & (bx.hi[2] >= s_lo_z[j]);
+        return any;
+      };
 
       PHASE_END(0);
       // ---- 2+3. gather the packet's block list and the per-query masks ----------------------
       int my_nblk = 0;  // lane = query: how many blocks of the packet's list I need
       int my_own_pos = 0;  // ... and where my own block (the one holding me) sits in my list
-      int nb = 0;
+      int nb = 0, scanned = 0;
       bool too_big = false;  // this packet-level does not fit the LDS lists
       for (int tree = 0; tree < 2 && !too_big; tree++) {
         const LbvhWideView &wv = a.wide[tree];
@@ -500,8 +534,7 @@ __global__ void __launch_bounds__(kTeamBlock) __attribute__((amdgpu_waves_per_eu
             LbvhBox bx = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
             if (valid) bx = wv.level[lvl][c];
             wave_node_tests += 64;
-            const bool ov = valid & (bx.lo[0] <= g_hi_x) & (bx.hi[0] >= g_lo_x) & (bx.lo[1] <= g_hi_y) &
-                            (bx.hi[1] >= g_lo_y) & (bx.lo[2] <= g_hi_z) & (bx.hi[2] >= g_lo_z);
+            const bool ov = valid & overlaps_packet(bx);
             const unsigned long long om = __ballot(ov);
             const int cnt = __popcll(om);
             if (lvl > 1) {
@@ -532,9 +565,16 @@ __global__ void __launch_bounds__(kTeamBlock) __attribute__((amdgpu_waves_per_eu
             bx_next = leaf_boxes(i + 1);
             const bool valid = first_child + lane <= last_block;
             wave_node_tests += 64;
-            const bool ov = valid & (bx.lo[0] <= g_hi_x) & (bx.hi[0] >= g_lo_x) & (bx.lo[1] <= g_hi_y) &
-                            (bx.hi[1] >= g_lo_y) & (bx.lo[2] <= g_hi_z) & (bx.hi[2] >= g_lo_z);
+            const bool ov = valid & overlaps_packet(bx);
             unsigned long long om = __ballot(ov);
+            // A packet of far-apart queries (outliers of a clustered set) has a union box that covers
+            // whole clusters none of its queries needs: testing those blocks one by one would keep
+            // this wave busy long after the others have finished.  The lane kernel walks per query.
+            scanned += __popcll(om);
+            if (scanned > kScanBudget) {
+              too_big = true;
+              break;
+            }
             // leaf blocks: which of my 64 queries need block c?  (lanes = queries, box by v_readlane)
             while (om) {
               const int src = __ffsll((long long)om) - 1;
@@ -721,21 +761,10 @@ bool Engine::team_kernel_supports(int k) { return k >= 1 && k <= 16; }
 // of the scene, the first level at which a box is expected to hold about k/2 other points.  Only
 // a work estimate -- every level is still resolved exactly.
 int Engine::first_step_estimate(const SolveArgs &sa) const {
-  double measure = 1.0;
-  int dims = 0;
-  for (int a = 0; a < 3; a++) {
-    const double e = (double)scene_[3 + a] - (double)scene_[a];
-    if (e > 0) {
-      measure *= e;
-      dims++;
-    }
-  }
-  if (dims == 0 || !(measure > 0)) return 1;
-  const double density = (double)bvh_.size() / measure;
-  double side = 2.0 * (double)sa.start_radius;
+  float radius = sa.start_radius;
   for (int m = 1; m < 3; m++) {
-    if (density * std::pow(side, dims) >= 0.5 * sa.k) return m;
-    side *= 2.0;
+    if (expected_box_population(radius) >= 0.5 * sa.k) return m;
+    radius *= 2.0f;
   }
   return 3;
 }
@@ -803,6 +832,8 @@ bool Engine::solve_team(const SolveArgs &sa, tknnSolveInfo *info, hipStream_t s)
     OWLMI_HIP(hipMemcpy(&wave_steps, counters_ + 15, sizeof wave_steps, hipMemcpyDeviceToHost));
     fprintf(stderr, "[team diag] block steps: %.3g wave steps x 4 teams for %.3g listed blocks (lockstep efficiency %.1f%%)\n",
             (double)wave_steps, (double)h_counters_[3] / LBVH_BLOCK, 100.0 * ((double)h_counters_[3] / LBVH_BLOCK) / (4.0 * (double)wave_steps));
+    fprintf(stderr, "[team diag] mean busy time per wave %.2f ms of %.2f ms kernel time (%d waves; s_memtime at 100 MHz)\n",
+            tot / 1e8 * 1e3 / blocks, ms, blocks);
     fprintf(stderr, "[team diag] wave-time shares: thresholds %.1f%%  gather %.1f%%  count %.1f%%  select %.1f%%  rest %.1f%%\n",
             100 * t[0] / tot, 100 * t[1] / tot, 100 * t[2] / tot, 100 * t[3] / tot, 100 * t[4] / tot);
   }
@@ -832,6 +863,9 @@ bool Engine::solve_team(const SolveArgs &sa, tknnSolveInfo *info, hipStream_t s)
     tknnSolveInfo tail;
     std::memset(&tail, 0, sizeof tail);
     continue_lane(sa, (int)h_counters_[9], &tail, s);
+    if (getenv("TKNN_VERBOSE"))
+      fprintf(stderr, "[team] %llu of %lld queries handed to lane rounds from level %llu on: team kernel %.2f ms, lane rounds %.2f ms (%d launches)\n",
+              handed, (long long)n, h_counters_[9], ms, tail.solve_ms, tail.dominant_kernel_launches);
     if (info) {
       info->rounds = std::max(info->rounds, tail.rounds);
       float radius = sa.start_radius;

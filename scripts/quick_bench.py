@@ -19,8 +19,15 @@ def main():
     kernels = [int(x) for x in (sys.argv[3] if len(sys.argv) > 3 else "1,2,3").split(",")]
     reps = int(sys.argv[4]) if len(sys.argv) > 4 else 3
     for n in sizes:
-        xyz = torch.from_numpy(datasets.uniform3d(n, seed=0)).cuda()
-        r0 = datasets.start_radius(n, k)
+        data = os.environ.get("QB_DATA", "uniform")
+        if data == "gmm":  # BASELINE config 3's point set
+            xyz, r0 = datasets.gaussian_mixture3d(n, components=64, sigma=0.02, seed=1), 0.0005
+        elif data == "taxi":
+            xyz, r0 = datasets.pad_to_3d(datasets.taxi_like2d(n, components=256, seed=2)), 0.0002
+        else:
+            xyz, r0 = datasets.uniform3d(n, seed=0), datasets.start_radius(n, k)
+        r0 = float(os.environ.get("QB_R0", r0))
+        xyz = torch.from_numpy(xyz).cuda()
         eng = TrueKNN()
         bi = eng.build(xyz)
         bi = eng.build(xyz)
@@ -36,6 +43,8 @@ def main():
                 wall = (time.perf_counter() - t) * 1e3
                 out = {kk: v for kk, v in r.items() if kk != "info"}
                 i = r["info"]
+                if os.environ.get("QB_INFO"):
+                    print("   ", i, flush=True)
                 best = wall if best is None else min(best, wall)
             print("  kernel=%d wall_ms=%.2f dev_ms=%.2f main_kernel_ms=%.2f rounds=%d isect/q=%.1f node_tests=%.3g point_tests=%.3g q/s=%.3g" % (
                 kern, best, i["solve_ms"], i["dominant_kernel_ms"], i["rounds"], i["total_intersections"] / n, i["node_tests"], i["point_tests"], n / best * 1e3), flush=True)
