@@ -541,10 +541,23 @@ __global__ void __launch_bounds__(kTeamBlock) __attribute__((amdgpu_waves_per_eu
               if (ov) stack[sp + t_rank(om)] = (lvl << 26) | c;
               sp += cnt;
             } else {
-              // children of `c` are leaf blocks; nodes are popped in descending Morton order, so filling
-              // the list downwards in descending rank keeps it ascending in memory
-              if (ov) stack[kTeamStack - 1 - nleaf - (cnt - 1 - t_rank(om))] = (lvl << 26) | c;
-              nleaf += cnt;
+              // children of `c` are leaf blocks.  Keep a survivor only if some single QUERY box reaches
+              // it (lanes = queries, the survivor's box by v_readlane): a dozen instructions that save
+              // its 64 blocks from being tested one by one where only the group box, not a query,
+              // overlapped.  Nodes are popped in descending Morton order and taken here from the
+              // highest lane down, so filling the list downwards keeps it ascending in memory.
+              unsigned long long rest = om;
+              while (rest) {
+                const int src = 63 - __builtin_clzll(rest);
+                rest &= ~(1ull << src);
+                const float b_lo_x = t_bcast(bx.lo[0], src), b_lo_y = t_bcast(bx.lo[1], src), b_lo_z = t_bcast(bx.lo[2], src);
+                const float b_hi_x = t_bcast(bx.hi[0], src), b_hi_y = t_bcast(bx.hi[1], src), b_hi_z = t_bcast(bx.hi[2], src);
+                const bool need = (b_lo_x <= hi_x) & (b_hi_x >= lo_x) & (b_lo_y <= hi_y) & (b_hi_y >= lo_y) &
+                                  (b_lo_z <= hi_z) & (b_hi_z >= lo_z);
+                if (__ballot(need) == 0ull) continue;
+                if (lane == 0) stack[kTeamStack - 1 - nleaf] = (lvl << 26) | (first_child + src);
+                nleaf++;
+              }
             }
             t_wave_sync();
             continue;
