@@ -60,7 +60,7 @@ class Engine {
   // lane rounds over the queries another kernel left with done_[slot] == 0, each from next_level_[slot]
   void continue_lane(const SolveArgs &sa, int first_level, tknnSolveInfo *info, hipStream_t s);
   void lane_rounds(const SolveArgs &sa, int first_level, bool fresh, tknnSolveInfo *info, hipStream_t s);
-  void solve_wave(const SolveArgs &sa, tknnSolveInfo *info, hipStream_t s);  // trueknn_wave.hip
+  void solve_wave(const SolveArgs &sa, tknnSolveInfo *info, hipStream_t s, bool only_unfinished = false);  // trueknn_wave.hip
   static bool wave_kernel_available();                                        // trueknn_wave.hip
   // trueknn_team.hip; returns false if a packet needed more leaf blocks than the kernel can name
   bool solve_team(const SolveArgs &sa, tknnSolveInfo *info, hipStream_t s);

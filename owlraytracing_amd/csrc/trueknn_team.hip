@@ -871,14 +871,22 @@ bool Engine::solve_team(const SolveArgs &sa, tknnSolveInfo *info, hipStream_t s)
   }
   const unsigned long long handed = h_counters_[8];
   if (handed) {
-    // stragglers whose candidate lists outgrew the LDS lists: the lane kernel finishes them,
-    // round by round, from the level at which each was handed over
+    // Stragglers whose candidate lists outgrew the LDS lists.  A few (outliers of a clustered set,
+    // whose boxes grow over whole clusters): per-round lane launches from the level at which each
+    // was handed over, with subtree counting.  Many (a start radius far too large for the density:
+    // hundreds of candidates per query from level 0 on): the wave-packet kernel, which streams
+    // candidate sets of any size, re-solves just those queries.
     tknnSolveInfo tail;
     std::memset(&tail, 0, sizeof tail);
-    continue_lane(sa, (int)h_counters_[9], &tail, s);
+    const char *force = getenv("TKNN_TEAM_TAIL");  // "lane" / "wave": measurements only
+    const bool by_wave = wave_kernel_available() && (force ? !strcmp(force, "wave") : handed * 4ull >= (unsigned long long)n);
+    if (by_wave)
+      solve_wave(sa, &tail, s, /*only_unfinished=*/true);
+    else
+      continue_lane(sa, (int)h_counters_[9], &tail, s);
     if (getenv("TKNN_VERBOSE"))
-      fprintf(stderr, "[team] %llu of %lld queries handed to lane rounds from level %llu on: team kernel %.2f ms, lane rounds %.2f ms (%d launches)\n",
-              handed, (long long)n, h_counters_[9], ms, tail.solve_ms, tail.dominant_kernel_launches);
+      fprintf(stderr, "[team] %llu of %lld queries handed over from level %llu on: team kernel %.2f ms, %s %.2f ms (%d launches)\n",
+              handed, (long long)n, h_counters_[9], ms, by_wave ? "wave kernel" : "lane rounds", tail.solve_ms, tail.dominant_kernel_launches);
     if (info) {
       info->rounds = std::max(info->rounds, tail.rounds);
       float radius = sa.start_radius;

@@ -43,6 +43,7 @@ struct WaveArgs {
   LbvhView bvh;
   LbvhView halo;      // second point set searched by every query (n == 0: none)
   int32_t *out_level; // n, caller order (may be null)
+  const uint8_t *skip_done;  // per sorted slot, may be null: queries another kernel has finished already
   int allow_unfinished;
   float start_radius;
   int k;
@@ -156,6 +157,10 @@ __global__ void __launch_bounds__(kWaveBlock) wave_packet_kernel(WaveArgs a) {
 
     const int32_t slot = g * 64 + lane;
     bool active = slot < bvh.n;
+    if (a.skip_done) {
+      active = active && !a.skip_done[slot];
+      if (__ballot(active) == 0ull) continue;
+    }
     LbvhPoint q = {0.f, 0.f, 0.f, -1};
     if (active) q = bvh.points[slot];
     float r = a.start_radius;
@@ -377,13 +382,14 @@ void debug_thresholds(const float *d_q, const float *d_r, int64_t n, float *d_lo
 
 bool Engine::wave_kernel_available() { return true; }
 
-void Engine::solve_wave(const SolveArgs &sa, tknnSolveInfo *info, hipStream_t s) {
+void Engine::solve_wave(const SolveArgs &sa, tknnSolveInfo *info, hipStream_t s, bool only_unfinished) {
   const int64_t n = bvh_.size();
   const int cap = list_capacity_for(sa.k);
   WaveArgs a;
   a.bvh = bvh_.view();
   a.halo = halo_view();
   a.out_level = sa.d_levels;
+  a.skip_done = only_unfinished ? done_ : nullptr;  // the team kernel's stragglers, solved from level 0
   a.allow_unfinished = sa.allow_unfinished ? 1 : 0;
   a.start_radius = sa.start_radius;
   a.k = sa.k;
@@ -415,7 +421,7 @@ void Engine::solve_wave(const SolveArgs &sa, tknnSolveInfo *info, hipStream_t s)
   const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>(want, (int64_t)prop.multiProcessorCount * per_cu));
 
   OWLMI_HIP(hipMemsetAsync(counters_, 0, 16 * sizeof(unsigned long long), s));
-  if (sa.d_levels) OWLMI_HIP(hipMemsetAsync(sa.d_levels, 0xff, (size_t)n * sizeof(int32_t), s));
+  if (sa.d_levels && !only_unfinished) OWLMI_HIP(hipMemsetAsync(sa.d_levels, 0xff, (size_t)n * sizeof(int32_t), s));
   OWLMI_HIP(hipEventRecord(ev_a_, s));
   switch (cap) {
     case 1: launch_wave<1>(a, blocks, s); break;
@@ -437,7 +443,10 @@ void Engine::solve_wave(const SolveArgs &sa, tknnSolveInfo *info, hipStream_t s)
   OWLMI_HIP(hipEventElapsedTime(&ms, ev_a_, ev_b_));
   if (h_counters_[5] & 2ull) {
     // LDS node stack exhausted on some packet (pathologically deep tree): redo with the lane kernel
-    solve_lane(sa, info, s);
+    if (only_unfinished)
+      continue_lane(sa, 0, info, s);  // done[] still names the stragglers; rows are simply rewritten
+    else
+      solve_lane(sa, info, s);
     return;
   }
   if (h_counters_[5] & 1ull) throw RoundsExceeded{};
