@@ -122,7 +122,13 @@ TKNN_API int tknnSolve(tknnEngine e, int k, float start_radius, int kernel, int 
  * tknnSolveEx: tknnSolve with options: d_levels (n, may be NULL) receives the 0-based radius level at
  *   which each query finished, or -1; with allow_unfinished != 0 reaching max_rounds is not an
  *   error: unfinished queries keep level -1, their rows are not written and info->unfinished counts
- *   them (the caller widens the halo and solves again). */
+ *   them (the caller widens the halo and solves again).
+ * tknnHaloSelect: the send side of the exchange.  d_boxes: nboxes x {lo xyz, hi xyz} fp32 closed
+ *   boxes (the peers' tile cells widened by the halo radius, rounded outward by the caller);
+ *   d_box_peer: the peer (0 <= peer < npeers <= 64) each box belongs to.  Count pass (d_rows NULL):
+ *   d_counts[npeers] = my points inside at least one box of each peer.  Write pass: d_rows receives
+ *   16-byte rows {x, y, z, id bits}, peer p's rows contiguous from row d_offsets[p] (the caller's
+ *   exclusive scan of the counts); the order inside a segment is unspecified. */
 typedef struct {
   int32_t k;
   float start_radius;
@@ -140,6 +146,9 @@ TKNN_API int tknnBuildIds(tknnEngine e, const float *d_xyz, const int32_t *d_ids
                           tknnBuildInfo *info, void *stream);
 TKNN_API int tknnSetHalo(tknnEngine e, const float *d_xyz, const int32_t *d_ids, int64_t m, void *stream);
 TKNN_API int tknnSolveEx(tknnEngine e, const tknnSolveOptions *options, tknnSolveInfo *info, void *stream);
+TKNN_API int tknnHaloSelect(tknnEngine e, const float *d_boxes, const int32_t *d_box_peer, int32_t nboxes,
+                            int32_t npeers, int64_t *d_counts, const int64_t *d_offsets, float *d_rows,
+                            void *stream);
 
 /* ---- exact kNN on request ---------------------------------------------------
  * tknnSolve reproduces the reference, whose rows are box-candidate kNN, not exact kNN: a query

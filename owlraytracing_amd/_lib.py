@@ -87,6 +87,8 @@ SIGNATURES = {
                                    ctypes.c_void_p]),
     "tknnSolveEx": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(SolveOptions), ctypes.POINTER(SolveInfo),
                                    ctypes.c_void_p]),
+    "tknnHaloSelect": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32,
+                                      ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     "tknnRepairExact": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_void_p, ctypes.c_void_p,
                                        ctypes.c_void_p, ctypes.POINTER(ctypes.c_int64), ctypes.c_void_p]),
     "tknnDbscan": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_float, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,

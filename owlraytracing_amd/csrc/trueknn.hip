@@ -284,6 +284,7 @@ Engine::~Engine() {
   if (isect_sorted_) (void)hipFree(isect_sorted_);
   if (next_level_) (void)hipFree(next_level_);
   if (counters_) (void)hipFree(counters_);
+  if (halo_mask_) (void)hipFree(halo_mask_);
   if (h_counters_) (void)hipHostFree(h_counters_);
   if (wave_ws_) (void)hipFree(wave_ws_);
   if (ev_a_) (void)hipEventDestroy(ev_a_);
@@ -578,6 +579,18 @@ int tknnSetHalo(tknnEngine e, const float *d_xyz, const int32_t *d_ids, int64_t 
   return guarded([&] {
     if (!e->impl.built()) throw owlmi::ArgError{TKNN_E_STATE, "tknnSetHalo: call tknnBuild first"};
     e->impl.set_halo(d_xyz, d_ids, m, (hipStream_t)stream);
+  });
+}
+
+int tknnHaloSelect(tknnEngine e, const float *d_boxes, const int32_t *d_box_peer, int32_t nboxes, int32_t npeers,
+                   int64_t *d_counts, const int64_t *d_offsets, float *d_rows, void *stream) {
+  if (!e || nboxes < 0 || (nboxes > 0 && (!d_boxes || !d_box_peer)) || (!d_rows && !d_counts) || (d_rows && !d_offsets)) {
+    g_last_error = "tknnHaloSelect: need boxes with their peers, and counts (count pass) or offsets + rows (write pass)";
+    return TKNN_E_ARG;
+  }
+  return guarded([&] {
+    if (!e->impl.built()) throw owlmi::ArgError{TKNN_E_STATE, "tknnHaloSelect: call tknnBuild first"};
+    e->impl.halo_select(d_boxes, d_box_peer, nboxes, npeers, d_counts, d_offsets, d_rows, (hipStream_t)stream);
   });
 }
 

@@ -45,6 +45,9 @@ class Engine {
   void build(const float *d_xyz, const int32_t *d_ids, int64_t n, tknnBuildInfo *info, hipStream_t s);
   void set_halo(const float *d_xyz, const int32_t *d_ids, int64_t m, hipStream_t s);
   LbvhView halo_view() const;
+  // halo_select.hip: my points inside any box of each peer, as 16-byte wire rows (count pass: d_rows == nullptr)
+  void halo_select(const float *d_boxes, const int32_t *d_box_peer, int32_t nboxes, int32_t npeers, int64_t *d_counts,
+                   const int64_t *d_offsets, float *d_rows, hipStream_t s);
   double expected_box_population(float radius) const;
   void solve(const SolveArgs &sa, int kernel, tknnSolveInfo *info, hipStream_t s);
   // rewrites the rows whose k-th distance exceeds their final box half-width with exact kNN; returns how many
@@ -80,6 +83,8 @@ class Engine {
   void *wave_ws_ = nullptr;
   size_t wave_ws_bytes_ = 0;
   int wave_leaf_max_ = 16;  // subtrees of at most this many points are streamed as one range (TKNN_LEAF_MAX)
+  unsigned long long *halo_mask_ = nullptr;  // per leaf block: peers it may have points for (+ 64 cursors)
+  int64_t halo_mask_cap_ = 0;
   hipEvent_t ev_a_ = nullptr, ev_b_ = nullptr;
 };
 

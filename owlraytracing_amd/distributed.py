@@ -20,6 +20,9 @@ path shards naturally -- queries are independent -- with ONE real exchange step:
 One process per GPU (torch.distributed, backend "nccl" = RCCL on ROCm); with backend "gloo" the
 same code runs with host-staged messages (CPU tests, or several ranks sharing one GPU).
 """
+import os
+import time
+
 import numpy as np
 import torch
 import torch.distributed as dist
@@ -98,7 +101,7 @@ class ShardedTrueKNN:
     inject a checker-backed stand-in to run the partition / halo / validity logic on CPU ranks.
     """
 
-    def __init__(self, device, kernel=_lib.KERNEL_AUTO, engine_factory=None, group=None, halo_levels=2):
+    def __init__(self, device, kernel=_lib.KERNEL_AUTO, engine_factory=None, group=None, halo_levels=None):
         self.device = torch.device(device)
         self.kernel = kernel
         self.comm = _Comm(group)
@@ -106,7 +109,11 @@ class ShardedTrueKNN:
             from .trueknn import TrueKNN
             engine_factory = lambda dev: TrueKNN(device=dev.index)  # noqa: E731
         self.engine = engine_factory(self.device)
-        self.halo_levels = halo_levels  # first halo radius = start_radius * 2**halo_levels
+        # first halo radius = start_radius * 2**halo_levels; None: from the density of the set, the level
+        # at which a box is expected to hold 32 k points (nearly every query has finished by then, so
+        # one exchange and one solve do; stragglers still widen the halo and go again)
+        self.halo_levels = halo_levels
+        self.extent = None      # (3,) float64 extents of the whole set
         self.points = None      # (m,3) float32 owned points, on self.device
         self.ids = None         # (m,) int32 global ids of the owned points
         self.tile_boxes = None  # (W, MAX_CELLS, 6) float64 on the host: boxes of every rank's Morton cells
@@ -114,6 +121,7 @@ class ShardedTrueKNN:
         self.cell_slices = None  # [(start, end)] of my cells in self.points
         self.n_total = 0
         self.last = None
+        self.profile = bool(os.environ.get("TKNN_SHARD_PROFILE"))  # per-phase wall times in info (adds syncs)
 
     # ---- one-time distribution -------------------------------------------------------------
     def load_counter_based(self, n_total, seed=0):
@@ -138,6 +146,7 @@ class ShardedTrueKNN:
         comm.all_reduce(lo, dist.ReduceOp.MIN)
         comm.all_reduce(hi, dist.ReduceOp.MAX)
         extent = float((hi - lo).max())
+        self.extent = (hi - lo).cpu()
         codes = morton63(points, lo, extent)
         order = torch.argsort(codes)
         codes, points, ids = codes[order], points[order], ids[order]
@@ -195,9 +204,27 @@ class ShardedTrueKNN:
         boxes widened in float64 (radius, a relative 1e-5, an ulp-of-coordinate margin) and rounded
         OUTWARD, so the selection can only err on the side of sending a point too many."""
         comm, dev = self.comm, self.device
+        reach = float(radius) * (1.0 + 1e-5) + 1e-30
+        if hasattr(self.engine, "halo_select"):
+            # the engine's kernels do the selection on its own Morton-sorted points: widened peer boxes
+            # in, per-peer contiguous wire rows out (tknnHaloSelect)
+            boxes, owner = [], []
+            for peer in range(comm.world):
+                if peer == comm.rank:
+                    continue
+                pb = self.tile_boxes[peer]
+                pb = pb[pb[:, 0] <= pb[:, 3]]  # drop empty slots
+                if len(pb) == 0:
+                    continue
+                lo, hi = self._widen(pb, reach)
+                boxes.append(torch.cat([lo, hi], dim=1))
+                owner.append(torch.full((len(pb),), peer, dtype=torch.int32))
+            if not boxes:
+                return [self._rows[:0] for _ in range(comm.world)]
+            rows, counts = self.engine.halo_select(torch.cat(boxes), torch.cat(owner), comm.world)
+            return list(torch.split(rows, counts))
         rows = self._rows
         blocks = []
-        reach = float(radius) * (1.0 + 1e-5) + 1e-30
         mine = self.cell_boxes  # (C,6) float64, host
         for peer in range(comm.world):
             if peer == comm.rank:
@@ -209,10 +236,8 @@ class ShardedTrueKNN:
             lo64, hi64 = pb[:, :3] - reach - 1e-6 * mag, pb[:, 3:] + reach + 1e-6 * mag
             # which of my cells meet any widened peer box (host)
             meet = ((mine[:, None, :3] <= hi64[None]) & (mine[:, None, 3:] >= lo64[None])).all(dim=2)  # (C,P)
-            lo = lo64.float()
-            hi = hi64.float()
-            lo = torch.where(lo.double() > lo64, torch.nextafter(lo, torch.full_like(lo, -float("inf"))), lo).to(dev)
-            hi = torch.where(hi.double() < hi64, torch.nextafter(hi, torch.full_like(hi, float("inf"))), hi).to(dev)
+            lo, hi = self._widen(pb, reach)
+            lo, hi = lo.to(dev), hi.to(dev)
             picked = []
             for c, (s0, s1) in enumerate(self.cell_slices):
                 which = torch.nonzero(meet[c]).flatten()
@@ -225,27 +250,64 @@ class ShardedTrueKNN:
             blocks.append(torch.cat(picked, dim=0) if picked else rows[:0])
         return blocks
 
+    @staticmethod
+    def _widen(pb, reach):
+        """float32 boxes containing pb (float64 cell boxes) widened by `reach`, a relative 1e-6 and
+        rounded OUTWARD: the selection can only err on the side of sending a point too many."""
+        mag = pb.abs().max(dim=1, keepdim=True).values
+        lo64, hi64 = pb[:, :3] - reach - 1e-6 * mag, pb[:, 3:] + reach + 1e-6 * mag
+        lo, hi = lo64.float(), hi64.float()
+        lo = torch.where(lo.double() > lo64, torch.nextafter(lo, torch.full_like(lo, -float("inf"))), lo)
+        hi = torch.where(hi.double() < hi64, torch.nextafter(hi, torch.full_like(hi, float("inf"))), hi)
+        return lo, hi
+
     def solve(self, k, start_radius, max_rounds=64, want_fb=False):
         comm, dev = self.comm, self.device
         r0 = np.float32(start_radius)
         level_cap = self.halo_levels
+        if level_cap is None:
+            ext = [float(e) for e in self.extent if float(e) > 0]
+            measure = float(np.prod(ext)) if ext else 0.0
+            level_cap = 0
+            if measure > 0:
+                density = self.n_total / measure
+                while level_cap < 6 and density * (2.0 * float(r0) * 2 ** level_cap) ** len(ext) < 32.0 * k:
+                    level_cap += 1
         exchanges, halo_points = 0, 0
+        phase = {"select": 0.0, "exchange": 0.0, "halo_build": 0.0, "solve": 0.0, "reduce": 0.0}
+        profile = self.profile
+
+        def lap(name, t0):
+            if profile:
+                if dev.type == "cuda":
+                    torch.cuda.synchronize(dev)
+                phase[name] += (time.perf_counter() - t0) * 1e3
+            return time.perf_counter()
+
         while True:
             halo_radius = np.float32(r0)
             for _ in range(level_cap):
                 halo_radius = np.float32(halo_radius * np.float32(2))
-            got = comm.exchange_rows(self._halo_blocks(halo_radius), 4, torch.float32, dev)
+            t = time.perf_counter()
+            blocks = self._halo_blocks(halo_radius)
+            t = lap("select", t)
+            got = comm.exchange_rows(blocks, 4, torch.float32, dev)
             got[comm.rank] = got[comm.rank][:0]
             halo = torch.cat(got, dim=0)
+            t = lap("exchange", t)
             exchanges += 1
             halo_points = len(halo)
             self.engine.set_halo(halo[:, :3].contiguous(), halo[:, 3].contiguous().view(torch.int32))
+            t = lap("halo_build", t)
             # levels 0..level_cap are exact with this halo; stop there and see who is left
             res = self.engine.solve(k, float(r0), kernel=self.kernel, max_rounds=level_cap + 1,
                                     want_fb=want_fb, want_levels=True, allow_unfinished=True)
+            t = lap("solve", t)
             left = torch.tensor([int(res["info"]["unfinished"])], dtype=torch.int64, device=dev)
             comm.all_reduce(left, dist.ReduceOp.SUM)
-            if int(left.item()) == 0:
+            done = int(left.item()) == 0
+            t = lap("reduce", t)
+            if done:
                 break
             if level_cap + 1 >= max_rounds:
                 raise _lib.TknnError(-4, "max_rounds reached with unfinished queries")
@@ -257,6 +319,8 @@ class ShardedTrueKNN:
         info["halo_exchanges"] = exchanges
         info["halo_points"] = halo_points
         info["halo_levels"] = level_cap
+        if profile:
+            info["phase_ms"] = phase
         self.last = res
         self.last["info"] = info
         return info

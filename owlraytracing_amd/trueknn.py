@@ -96,6 +96,28 @@ class TrueKNN:
                                              ctypes.c_void_p(ids.data_ptr()), points.shape[0], self._stream()))
             torch.cuda.current_stream(self.device).synchronize()  # the engine copied what it needs
 
+    def halo_select(self, boxes, box_peer, npeers):
+        """Send side of the halo exchange: my points inside any of ``boxes`` (m,6 float32 closed boxes,
+        lo xyz hi xyz) of each peer ``box_peer[j]``.  Returns (rows, counts): rows (sum(counts), 4)
+        float32 wire rows x y z id-bits with peer p's rows contiguous (in peer order), counts a
+        python list of length npeers.  Row order inside a peer's segment is unspecified."""
+        torch = self._torch
+        with torch.cuda.device(self.device):
+            dev = self.device
+            boxes = torch.as_tensor(boxes, dtype=torch.float32, device=dev).contiguous().view(-1, 6)
+            box_peer = torch.as_tensor(box_peer, dtype=torch.int32, device=dev).contiguous()
+            counts = torch.empty(npeers, dtype=torch.int64, device=dev)
+            args = (self._h, ctypes.c_void_p(boxes.data_ptr()), ctypes.c_void_p(box_peer.data_ptr()), int(len(box_peer)), int(npeers))
+            _lib.check(self._lib.tknnHaloSelect(*args, ctypes.c_void_p(counts.data_ptr()), None, None, self._stream()))
+            host_counts = counts.cpu()  # the caller needs them on the host anyway (message sizes)
+            offsets = (torch.cumsum(host_counts, 0) - host_counts).to(dev)
+            total = int(host_counts.sum())
+            rows = torch.empty((total, 4), dtype=torch.float32, device=dev)
+            if total:
+                _lib.check(self._lib.tknnHaloSelect(*args, None, ctypes.c_void_p(offsets.data_ptr()),
+                                                    ctypes.c_void_p(rows.data_ptr()), self._stream()))
+            return rows, host_counts.tolist()
+
     def solve(self, k, start_radius, kernel=_lib.KERNEL_AUTO, max_rounds=64, want_fb=False,
               out=None, want_levels=False, allow_unfinished=False):
         """Returns dict(idx (n,k) int32, dist (n,k) f32, intersections (n,) int64[, fb (n*k*24,) uint8])

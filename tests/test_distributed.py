@@ -69,3 +69,44 @@ def test_four_ranks_sharing_one_gpu_cross_z_curve_jumps(tmp_path):
     got = _run("hip", 4, n, k, "uniform", tmp_path, 29651, {"HALO_LEVELS": "2"})
     _check(got, "uniform", n, k)
     assert int(got["halo_points"]) < int(got["tile"]) // 2
+
+
+@pytest.mark.gpu
+def test_halo_select_matches_a_plain_selection():
+    """tknnHaloSelect (send side of the exchange): per peer, exactly the points inside any of its boxes,
+    each once, as wire rows x y z id-bits."""
+    import torch
+
+    from owlraytracing_amd import datasets
+    from owlraytracing_amd.trueknn import TrueKNN
+    n, npeers = 150_000, 5
+    pts = datasets.uniform3d(n, seed=31)
+    pts[7] = np.nan  # never selected
+    ids = (np.arange(n, dtype=np.int32) * 3 + 11)
+    rng = np.random.default_rng(32)
+    lo = rng.random((40, 3)).astype(np.float32) * 0.9
+    hi = lo + rng.random((40, 3)).astype(np.float32) * 0.15
+    hi[0] = lo[0]  # a degenerate box
+    lo[1], hi[1] = pts[100], pts[100]  # a box that is exactly one point: closed boundaries
+    peer = rng.integers(0, npeers, 40).astype(np.int32)
+    peer[peer == 2] = 3  # a peer without boxes
+    eng = TrueKNN()
+    eng.build(torch.from_numpy(pts).cuda(), torch.from_numpy(ids).cuda())
+    rows, counts = eng.halo_select(torch.from_numpy(np.concatenate([lo, hi], axis=1)), torch.from_numpy(peer), npeers)
+    rows = rows.cpu()
+    assert len(counts) == npeers and sum(counts) == len(rows) and counts[2] == 0
+    start = 0
+    for p in range(npeers):
+        seg = rows[start:start + counts[p]]
+        start += counts[p]
+        got_ids = np.sort(seg[:, 3].contiguous().view(torch.int32).numpy())
+        inside = np.zeros(n, bool)
+        for j in np.nonzero(peer == p)[0]:
+            inside |= np.all((pts >= lo[j]) & (pts <= hi[j]), axis=1)
+        assert np.array_equal(got_ids, np.sort(ids[inside])), p
+        # coordinates travel with their ids
+        back = {int(i): tuple(r) for i, r in zip(seg[:, 3].contiguous().view(torch.int32).numpy(), seg[:, :3].numpy())}
+        for i in list(back)[:50]:
+            assert back[i] == tuple(pts[(i - 11) // 3])
+    assert ids[100] in rows[:, 3].contiguous().view(torch.int32).numpy()
+    eng.close()
