@@ -14,6 +14,14 @@
 //   2. union: every core point unites with each core neighbour of smaller index (lock-free
 //      union-find; the smaller index stays root, so a root is its cluster's smallest core index)
 //   3. labels: roots ranked by an exclusive scan; border points take the smallest adjacent root
+// TIGHT NODES keep step 2 from costing O(n x neighbours) in dense sets (BASELINE config 3: 5 000
+// neighbours per point).  A tree node whose box diagonal is below eps holds points that are pairwise
+// within eps, so its core points are one cluster: every core point unites with the first core point
+// of the first tight node on its own root path, and a traversal that meets a tight node settles it
+// as a whole -- farthest corner within eps: unite with that representative; nearest face beyond
+// eps: nothing; otherwise test its core points one by one until the first within eps.  The
+// components, and so the labels, are those of the full neighbour graph.  Step 3 and the full
+// neighbour counts use the same node tests (a node inside the sphere is counted, not walked).
 // Union-find reads/writes go through agent-scope atomics: a workgroup's L1 (and another XCD's L2)
 // would otherwise keep serving a stale parent and a failed CAS could retry forever.
 #include "trueknn_engine.h"
@@ -37,7 +45,23 @@ struct DbArgs {
   int32_t *parent;       // per caller index
   int32_t *rank;         // per caller index: cluster label of a root
   int32_t *labels;       // per caller index
+  const int32_t *next_core;  // per sorted slot (+1 sentinel): first core slot at or after it, n if none
+  float eps_in2, eps_out2;   // eps^2 (1 -+ 1e-5): below / above these, fp32 distance arithmetic cannot disagree
 };
+
+// squared distances from q to the farthest and the nearest point of a box
+__device__ __forceinline__ void box_dist2(const LbvhNode &nd, const LbvhPoint &q, float &far2, float &near2) {
+  const float ax = fmaxf(fabsf(q.x - nd.lo[0]), fabsf(q.x - nd.hi[0])), ay = fmaxf(fabsf(q.y - nd.lo[1]), fabsf(q.y - nd.hi[1])),
+              az = fmaxf(fabsf(q.z - nd.lo[2]), fabsf(q.z - nd.hi[2]));
+  const float bx = fmaxf(fmaxf(nd.lo[0] - q.x, q.x - nd.hi[0]), 0.f), by = fmaxf(fmaxf(nd.lo[1] - q.y, q.y - nd.hi[1]), 0.f),
+              bz = fmaxf(fmaxf(nd.lo[2] - q.z, q.z - nd.hi[2]), 0.f);
+  far2 = ax * ax + ay * ay + az * az;
+  near2 = bx * bx + by * by + bz * bz;
+}
+__device__ __forceinline__ bool node_is_tight(const LbvhNode &nd, float eps_in2) {
+  const float ex = nd.hi[0] - nd.lo[0], ey = nd.hi[1] - nd.lo[1], ez = nd.hi[2] - nd.lo[2];
+  return ex * ex + ey * ey + ez * ez <= eps_in2;  // NaN boxes (none: fit ignores NaN points) would be "not tight"
+}
 
 __device__ __forceinline__ int32_t uf_load(int32_t *p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -62,9 +86,12 @@ __device__ __forceinline__ void uf_unite(int32_t *parent, int32_t a, int32_t b) 
   }
 }
 
-// visits every point within the sphere; f(point, slot) returns false to stop early
+// Walks the tree for the CORE neighbours of q, tight nodes settled as a whole: calls
+// f(representative's id) for every tight node that has a core point within eps of q (its first core
+// point stands for all of them) and for every core point within eps reached as a leaf.  `own_slot`
+// (or -1) names q's own sorted slot: the tight node holding it is skipped.
 template <typename F>
-__device__ __forceinline__ void for_each_neighbour(const DbArgs &a, const LbvhPoint &q, F f) {
+__device__ __forceinline__ void for_each_core_group(const DbArgs &a, const LbvhPoint &q, int32_t own_slot, F f) {
   const LbvhView &bvh = a.bvh;
   const float r = a.eps_wide;
   int32_t ref = bvh.root;
@@ -73,13 +100,35 @@ __device__ __forceinline__ void for_each_neighbour(const DbArgs &a, const LbvhPo
       const LbvhNode nd = bvh.nodes[ref];
       const bool hit = (nd.lo[0] - r <= q.x) & (q.x <= nd.hi[0] + r) & (nd.lo[1] - r <= q.y) & (q.y <= nd.hi[1] + r) &
                        (nd.lo[2] - r <= q.z) & (q.z <= nd.hi[2] + r);
+      if (hit && node_is_tight(nd, a.eps_in2)) {
+        const int32_t first = lbvh_first(ref, nd.other), last = lbvh_last(ref, nd.other);
+        int32_t s = a.next_core[first];
+        if (s <= last && !(first <= own_slot && own_slot <= last)) {
+          float far2, near2;
+          box_dist2(nd, q, far2, near2);
+          if (far2 <= a.eps_in2) {
+            f(bvh.points[s].id);
+          } else if (near2 <= a.eps_out2) {
+            const int32_t rep_id = bvh.points[s].id;
+            for (; s <= last; s = a.next_core[s + 1]) {
+              const LbvhPoint p = bvh.points[s];
+              if (knn_sqrt(knn_dist2(p.x, p.y, p.z, q.x, q.y, q.z)) <= a.eps) {
+                f(rep_id);
+                break;
+              }
+            }
+          }
+        }
+        ref = bvh.rope_node[ref];
+        continue;
+      }
       ref = hit ? lbvh_left_ref(ref, nd) : bvh.rope_node[ref];
     } else {
       const int32_t slot = ~ref;
-      const LbvhPoint p = bvh.points[slot];
-      const float d = knn_sqrt(knn_dist2(p.x, p.y, p.z, q.x, q.y, q.z));
-      if (d <= a.eps)
-        if (!f(p, slot)) return;
+      if (a.core_sorted[slot] && slot != own_slot) {
+        const LbvhPoint p = bvh.points[slot];
+        if (knn_sqrt(knn_dist2(p.x, p.y, p.z, q.x, q.y, q.z)) <= a.eps) f(p.id);
+      }
       ref = bvh.rope_leaf[slot];
     }
   }
@@ -88,13 +137,37 @@ __device__ __forceinline__ void for_each_neighbour(const DbArgs &a, const LbvhPo
 __global__ void __launch_bounds__(kDbBlock) db_core_kernel(DbArgs a) {
   const int32_t t = blockIdx.x * kDbBlock + threadIdx.x;
   if (t >= a.bvh.n) return;
-  const LbvhPoint q = a.bvh.points[t];
+  const LbvhView &bvh = a.bvh;
+  const LbvhPoint q = bvh.points[t];
   int32_t cnt = 0;
   const int stop_at = a.want_counts ? 0x7fffffff : a.min_pts;
-  for_each_neighbour(a, q, [&](const LbvhPoint &, int32_t) {
-    cnt++;
-    return cnt < stop_at;
-  });
+  const int32_t clean_end = bvh.n - (bvh.nan_count ? *bvh.nan_count : 0);  // NaN points sort last
+  const float r = a.eps_wide;
+  int32_t ref = bvh.root;
+  while (ref != LBVH_END && cnt < stop_at) {
+    if (ref >= 0) {
+      const LbvhNode nd = bvh.nodes[ref];
+      const bool hit = (nd.lo[0] - r <= q.x) & (q.x <= nd.hi[0] + r) & (nd.lo[1] - r <= q.y) & (q.y <= nd.hi[1] + r) &
+                       (nd.lo[2] - r <= q.z) & (q.z <= nd.hi[2] + r);
+      if (hit) {
+        // a node inside the sphere is counted, not walked
+        float far2, near2;
+        box_dist2(nd, q, far2, near2);
+        const int32_t last = lbvh_last(ref, nd.other);
+        if (far2 <= a.eps_in2 && last < clean_end) {
+          cnt += last - lbvh_first(ref, nd.other) + 1;
+          ref = bvh.rope_node[ref];
+          continue;
+        }
+      }
+      ref = hit ? lbvh_left_ref(ref, nd) : bvh.rope_node[ref];
+    } else {
+      const int32_t slot = ~ref;
+      const LbvhPoint p = bvh.points[slot];
+      if (knn_sqrt(knn_dist2(p.x, p.y, p.z, q.x, q.y, q.z)) <= a.eps) cnt++;
+      ref = bvh.rope_leaf[slot];
+    }
+  }
   const uint8_t is_core = cnt >= a.min_pts;
   a.core_sorted[t] = is_core;
   if (a.core) a.core[q.id] = is_core;
@@ -102,13 +175,48 @@ __global__ void __launch_bounds__(kDbBlock) db_core_kernel(DbArgs a) {
   a.parent[q.id] = q.id;
 }
 
+// next_core[s] = first core slot >= s (n if none): with rank[s] = number of core slots before s (an
+// exclusive sum of the flags) and pos[r] = slot of the r-th core point, next_core[s] = pos[rank[s]]
+__global__ void __launch_bounds__(kDbBlock) db_core_flag_kernel(DbArgs a, int32_t *flag) {
+  const int32_t t = blockIdx.x * kDbBlock + threadIdx.x;
+  if (t < a.bvh.n) flag[t] = a.core_sorted[t];
+}
+__global__ void __launch_bounds__(kDbBlock) db_core_pos_kernel(DbArgs a, const int32_t *rank, int32_t *pos) {
+  const int32_t t = blockIdx.x * kDbBlock + threadIdx.x;
+  if (t < a.bvh.n && a.core_sorted[t]) pos[rank[t]] = t;
+}
+__global__ void __launch_bounds__(kDbBlock) db_next_core_kernel(DbArgs a, const int32_t *rank, const int32_t *pos,
+                                                                int32_t *next_core) {
+  const int32_t t = blockIdx.x * kDbBlock + threadIdx.x;
+  if (t > a.bvh.n) return;
+  if (t == a.bvh.n) {
+    next_core[t] = a.bvh.n;
+    return;
+  }
+  // a slot after the last core point has rank = number of core points: pos[] holds n there
+  const int32_t v = pos[rank[t]];
+  next_core[t] = v < a.bvh.n ? v : a.bvh.n;
+}
+
 __global__ void __launch_bounds__(kDbBlock) db_union_kernel(DbArgs a) {
   const int32_t t = blockIdx.x * kDbBlock + threadIdx.x;
   if (t >= a.bvh.n || !a.core_sorted[t]) return;
-  const LbvhPoint q = a.bvh.points[t];
-  for_each_neighbour(a, q, [&](const LbvhPoint &p, int32_t slot) {
-    if (p.id < q.id && a.core_sorted[slot]) uf_unite(a.parent, q.id, p.id);
-    return true;
+  const LbvhView &bvh = a.bvh;
+  const LbvhPoint q = bvh.points[t];
+  // the first tight node on my own root path: its core points are one cluster, held together by its
+  // first core point
+  int32_t node = bvh.root;
+  while (node >= 0) {
+    const LbvhNode nd = bvh.nodes[node];
+    if (node_is_tight(nd, a.eps_in2)) {
+      const int32_t s = a.next_core[lbvh_first(node, nd.other)];  // <= t: I am core and inside
+      if (s != t) uf_unite(a.parent, q.id, bvh.points[s].id);
+      break;
+    }
+    node = t <= nd.split ? lbvh_left_ref(node, nd) : lbvh_right_ref(node, nd);
+  }
+  for_each_core_group(a, q, t, [&](int32_t id) {
+    if (id != q.id) uf_unite(a.parent, q.id, id);
   });
 }
 
@@ -134,12 +242,9 @@ __global__ void __launch_bounds__(kDbBlock) db_label_kernel(DbArgs a) {
   if (a.core_sorted[t]) {
     root = uf_find(a.parent, q.id);
   } else {
-    for_each_neighbour(a, q, [&](const LbvhPoint &p, int32_t slot) {
-      if (a.core_sorted[slot]) {
-        const int32_t r = uf_find(a.parent, p.id);
-        if (root < 0 || r < root) root = r;
-      }
-      return true;
+    for_each_core_group(a, q, -1, [&](int32_t id) {
+      const int32_t r = uf_find(a.parent, id);
+      if (root < 0 || r < root) root = r;
     });
   }
   a.labels[q.id] = root < 0 ? -1 : a.rank[root];
@@ -151,7 +256,7 @@ void Engine::dbscan(float eps, int min_pts, int32_t *d_labels, uint8_t *d_core, 
                     tknnDbscanInfo *info, hipStream_t s) {
   const int64_t n = bvh_.size();
   // scratch: core flags per slot, parent, root flags, ranks
-  const size_t need = (((size_t)n * (1 + 4 + 4 + 4)) + 255) / 256 * 256;
+  const size_t need = (((size_t)n * (1 + 4 + 4 + 4 + 4)) + 16 + 255) / 256 * 256;  // + next_core, + two sentinels
   size_t scan_bytes = 0;
   OWLMI_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, (int32_t *)nullptr, (int32_t *)nullptr, (int)n, s));
   if (need + scan_bytes > wave_ws_bytes_) {
@@ -169,8 +274,12 @@ void Engine::dbscan(float eps, int min_pts, int32_t *d_labels, uint8_t *d_core, 
   a.want_counts = d_counts != nullptr;
   a.parent = (int32_t *)ws;
   int32_t *is_root = (int32_t *)(ws + (size_t)n * 4);
-  a.rank = (int32_t *)(ws + (size_t)n * 8);
-  a.core_sorted = (uint8_t *)(ws + (size_t)n * 12);
+  a.rank = (int32_t *)(ws + (size_t)n * 8);  // n + 1 entries
+  int32_t *next_core = (int32_t *)(ws + (size_t)n * 12 + 4);  // n + 1 entries
+  a.core_sorted = (uint8_t *)(ws + (size_t)n * 16 + 8);
+  a.next_core = next_core;
+  a.eps_in2 = eps * eps * (1.0f - 1e-5f);
+  a.eps_out2 = eps * eps * (1.0f + 1e-5f);
   void *scan_tmp = ws + need;
   a.core = d_core;
   a.counts = d_counts;
@@ -179,6 +288,17 @@ void Engine::dbscan(float eps, int min_pts, int32_t *d_labels, uint8_t *d_core, 
   hipEvent_t e0 = ev_a_, e1 = ev_b_;
   OWLMI_HIP(hipEventRecord(e0, s));
   hipLaunchKernelGGL(db_core_kernel, dim3(blocks), dim3(kDbBlock), 0, s, a);
+  {
+    // next_core: flags -> exclusive sum (rank of a slot among the core slots) -> slot of the r-th core
+    // point -> first core slot at or after each slot.  is_root / rank are free until the unions are done.
+    int32_t *flag = a.rank, *core_rank = is_root, *pos = a.rank;
+    const unsigned blocks1 = (unsigned)((n + 1 + kDbBlock - 1) / kDbBlock);
+    hipLaunchKernelGGL(db_core_flag_kernel, dim3(blocks), dim3(kDbBlock), 0, s, a, flag);
+    OWLMI_HIP(hipcub::DeviceScan::ExclusiveSum(scan_tmp, scan_bytes, flag, core_rank, (int)n, s));
+    OWLMI_HIP(hipMemsetAsync(pos, 0x7f, ((size_t)n + 1) * sizeof(int32_t), s));  // 0x7f7f7f7f: "none", clamped below
+    hipLaunchKernelGGL(db_core_pos_kernel, dim3(blocks), dim3(kDbBlock), 0, s, a, core_rank, pos);
+    hipLaunchKernelGGL(db_next_core_kernel, dim3(blocks1), dim3(kDbBlock), 0, s, a, core_rank, pos, next_core);
+  }
   hipLaunchKernelGGL(db_union_kernel, dim3(blocks), dim3(kDbBlock), 0, s, a);
   hipLaunchKernelGGL(db_flatten_kernel, dim3(blocks), dim3(kDbBlock), 0, s, a, is_root);
   OWLMI_HIP(hipGetLastError());
