@@ -154,9 +154,8 @@ __device__ __forceinline__ uint32_t t_team_shr1(uint32_t v, uint32_t fill) {
   return (uint32_t)__builtin_amdgcn_update_dpp((int)fill, (int)v, 0x111 /*row_shr:1*/, 0xf, 0xf, false);
 }
 
-// acc + (flag ? 1 : 0) as ONE add-with-carry on the compare mask (the compiler's select + add is two)
-__device__ __forceinline__ uint32_t t_count(uint32_t acc, bool flag) {
-  const unsigned long long mask = __ballot(flag);
+// acc + (my bit of the wave mask) as ONE add-with-carry on the compare mask (the compiler's select + add is two)
+__device__ __forceinline__ uint32_t t_count(uint32_t acc, unsigned long long mask) {
   uint32_t out;
   asm("v_addc_co_u32_e64 %0, vcc, 0, %1, %2" : "=v"(out) : "v"(acc), "s"(mask) : "vcc");
   return out;
@@ -259,26 +258,27 @@ __device__ __forceinline__ void team_pass(const TeamArgs &a, const TeamLds &L, i
     uint32_t best_d = 0x7f7fffffu, best_i = 0u;  // KNN_EMPTY_KEY = {FLT_MAX, 0}
     float tau2 = INFINITY;
     // one block's test; `it` is wave-uniform
+    // Lane predicates are kept as 64-bit wave masks (SGPR pairs) from the compare to the branch: a
+    // bool that crosses a branch would be turned into a VGPR 0/1 and back, two VALU instructions each.
     auto process = [&](const LbvhPoint &p) {
       const float dx = p.x - t_qx, dy = p.y - t_qy, dz = p.z - t_qz;
       // NaN only if all three are (sentinels; lbvh.hip turns a point with any NaN coordinate into one)
       const float t = fmaxf(fmaxf(fabsf(dx), fabsf(dy)), fabsf(dz));
-      bool in = t <= in_below;
-      const bool maybe = !in && (t <= in_upto);
-      if (__ballot(maybe) != 0ull) in = in || (maybe && knn_in_box(p.x, p.y, p.z, t_r, t_qx, t_qy, t_qz));
-      const bool is_self = in && (p.id == t_qid);  // ids are unique and a query lies in its own box
-      cnt = t_count(cnt, in);
+      unsigned long long in_m = __ballot(t <= in_below);
+      const unsigned long long maybe_m = __ballot(t <= in_upto) & ~in_m;
+      if (maybe_m) in_m |= maybe_m & __ballot(knn_in_box(p.x, p.y, p.z, t_r, t_qx, t_qy, t_qz));
+      cnt = t_count(cnt, in_m);
       if (!SELECT && m > 1) {
-        bool in0 = t <= i0_below;
-        const bool maybe0 = !in0 && (t <= i0_upto);
-        if (__ballot(maybe0) != 0ull) in0 = in0 || (maybe0 && knn_in_box(p.x, p.y, p.z, r_inner, t_qx, t_qy, t_qz));
-        cnt_i0 = t_count(cnt_i0, in0);
+        unsigned long long in0_m = __ballot(t <= i0_below);
+        const unsigned long long maybe0_m = __ballot(t <= i0_upto) & ~in0_m;
+        if (maybe0_m) in0_m |= maybe0_m & __ballot(knn_in_box(p.x, p.y, p.z, r_inner, t_qx, t_qy, t_qz));
+        cnt_i0 = t_count(cnt_i0, in0_m);
       }
       if (SELECT) {
         const float d2 = t_dist2(dx, dy, dz);
-        bool pend = in && !is_self && (d2 <= tau2);
-        if (TKNN_DIAG_BUILD && (a.diag & 1)) pend = false;
-        unsigned long long pm = __ballot(pend);
+        // candidates other than the query itself (ids are unique) that pass the gate
+        unsigned long long pm = in_m & __ballot(p.id != t_qid) & __ballot(d2 <= tau2);
+        if (TKNN_DIAG_BUILD && (a.diag & 1)) pm = 0;
         if (pm) {
           // exact key of my candidate, then one team-parallel sorted insert per pending lane
           const uint32_t key_d = __float_as_uint(knn_sqrt(d2));
@@ -301,8 +301,7 @@ __device__ __forceinline__ void team_pass(const TeamArgs &a, const TeamLds &L, i
             const uint64_t nw = take_prev ? prev : (take_c ? c : cur);
             best_d = (uint32_t)(nw >> 32);
             best_i = (uint32_t)nw;
-            if (lane == src) pend = false;
-            pm = __ballot(pend);
+            pm &= ~__ballot(lane == src);  // the four lanes just served (a team without one names a lane that was not pending)
           } while (pm);
           // gate from the k-th best of my team
           const float w = __uint_as_float(t_lane_read(best_d, (team << 4) + a.k - 1));

@@ -11,6 +11,6 @@ git show $rev:owlraytracing_amd/csrc/trueknn_team.hip > diagobj/ab/trueknn_team_
 /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -fvisibility=hidden \
   -I../../include -I../../include/owl_shims -I. -Wno-unused-result -Wno-bitwise-instead-of-logical \
   -c diagobj/ab/trueknn_team_prev.hip -o diagobj/ab/team_prev.o
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC lbvh.o trueknn.o trueknn_wave.o diagobj/ab/team_prev.o dbscan.o owl_runtime.o \
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $(ls *.o | grep -v '^trueknn_team.o$') diagobj/ab/team_prev.o \
   -o ../libowl_mi355x_prev.so
 echo built ../libowl_mi355x_prev.so from $rev
