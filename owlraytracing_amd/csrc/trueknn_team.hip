@@ -149,9 +149,9 @@ __device__ __forceinline__ float t_team_max(float v) {
   v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x121 /*row_ror:1*/, 0xf, 0xf, false)));
   return v;
 }
-// my left neighbour's value inside the team (lane 0 of a team gets `fill`)
-__device__ __forceinline__ uint32_t t_team_shr1(uint32_t v, uint32_t fill) {
-  return (uint32_t)__builtin_amdgcn_update_dpp((int)fill, (int)v, 0x111 /*row_shr:1*/, 0xf, 0xf, false);
+// my left neighbour's value inside the team (lane 0 of a team gets 0: bound_ctrl)
+__device__ __forceinline__ uint32_t t_team_shr1(uint32_t v) {
+  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111 /*row_shr:1*/, 0xf, 0xf, true);
 }
 
 // acc + (my bit of the wave mask) as ONE add-with-carry on the compare mask (the compiler's select + add is two)
@@ -287,17 +287,14 @@ __device__ __forceinline__ void team_pass(const TeamArgs &a, const TeamLds &L, i
             const uint32_t pending_mine = (uint32_t)(pm >> (team * 16)) & 0xffffu;  // pending lanes of my team
             const bool has = pending_mine != 0u;
             const int src = (team << 4) + (has ? __ffs((int)pending_mine) - 1 : 0);
-            uint32_t cd = t_lane_read(key_d, src), ci = t_lane_read(key_i, src);
-            if (!has) {  // nothing to insert for this team in this step: a key that changes nothing
-              cd = 0xffffffffu;
-              ci = 0xffffffffu;
-            }
+            const uint32_t cd = t_lane_read(key_d, src), ci = t_lane_read(key_i, src);
             const uint64_t c = ((uint64_t)cd << 32) | ci;
             const uint64_t cur = ((uint64_t)best_d << 32) | best_i;
-            const uint32_t pd = t_team_shr1(best_d, 0u), pi = t_team_shr1(best_i, 0u);
+            const uint32_t pd = t_team_shr1(best_d), pi = t_team_shr1(best_i);
             const uint64_t prev = ((uint64_t)pd << 32) | pi;  // lane 0: key 0, never greater than c
-            const bool take_prev = (tl != 0) && (c < prev);
-            const bool take_c = c < cur;
+            // a team with nothing to insert in this step keeps its list (has is uniform per team)
+            const bool take_prev = has & (tl != 0) & (c < prev);
+            const bool take_c = has & (c < cur);
             const uint64_t nw = take_prev ? prev : (take_c ? c : cur);
             best_d = (uint32_t)(nw >> 32);
             best_i = (uint32_t)nw;
