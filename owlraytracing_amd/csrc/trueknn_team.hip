@@ -149,6 +149,14 @@ __device__ __forceinline__ float t_team_max(float v) {
   v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x121 /*row_ror:1*/, 0xf, 0xf, false)));
   return v;
 }
+// value of another lane of my row through DPP (quad permutes, mirrors) -- no LDS, no address register
+template <int CTRL>
+__device__ __forceinline__ uint32_t t_dpp(uint32_t v) {
+  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, true);
+}
+// value of lane (mine ^ 4): ds_swizzle in bit mode (and 0x1f, or 0, xor 4)
+__device__ __forceinline__ uint32_t t_xor4(uint32_t v) { return (uint32_t)__builtin_amdgcn_ds_swizzle((int)v, 0x101f); }
+
 // my left neighbour's value inside the team (lane 0 of a team gets 0: bound_ctrl)
 __device__ __forceinline__ uint32_t t_team_shr1(uint32_t v) {
   return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111 /*row_shr:1*/, 0xf, 0xf, true);
@@ -312,6 +320,45 @@ __device__ __forceinline__ void team_pass(const TeamArgs &a, const TeamLds &L, i
     // register, so picking the register (a scalar branch chain) happens once per chunk and an
     // entry costs one select + one cross-lane read.
     LbvhPoint pa = load_block_point<HALO>(own_pts, halo_pts, (int32_t)t_lane_read((uint32_t)e0, team << 4));
+    bool first_sorted = false;
+    if (SELECT && steps > 0) {
+      // The first block (the query's own) meets an empty list: every candidate in it would be inserted,
+      // one lock-step round each.  Instead the team SORTS its 16 keys (non-candidates = the empty key)
+      // with a bitonic network written so that every exchange keeps the smaller key in the lower lane:
+      // mirror within 2, 4, 8, 16 lanes followed by xor 4 / 2 / 1 steps -- ten exchanges of two
+      // cross-lane moves (DPP quad permutes and mirrors, one ds_swizzle) and a 64-bit compare each.
+      const LbvhPoint &p = pa;
+      const float dx = p.x - t_qx, dy = p.y - t_qy, dz = p.z - t_qz;
+      const float t = fmaxf(fmaxf(fabsf(dx), fabsf(dy)), fabsf(dz));
+      bool in = t <= in_below;
+      const bool maybe = !in && (t <= in_upto);
+      if (__ballot(maybe)) in = in || (maybe && knn_in_box(p.x, p.y, p.z, t_r, t_qx, t_qy, t_qz));
+      cnt = t_count(cnt, __ballot(in));
+      bool cand = in && (p.id != t_qid);
+      if (TKNN_DIAG_BUILD && (a.diag & 1)) cand = false;
+      best_d = cand ? __float_as_uint(knn_sqrt(t_dist2(dx, dy, dz))) : 0x7f7fffffu;
+      best_i = cand ? (uint32_t)p.id : 0u;
+      const bool up1 = (tl & 1) != 0, up2 = (tl & 2) != 0, up4 = (tl & 4) != 0, up8 = (tl & 8) != 0;
+      auto exchange = [&](uint32_t pd, uint32_t pi, bool upper) {
+        const uint64_t mine = ((uint64_t)best_d << 32) | best_i, other = ((uint64_t)pd << 32) | pi;
+        const bool take = (other < mine) != upper;  // lower lane: the smaller key; upper lane: the larger (equal: either)
+        best_d = take ? pd : best_d;
+        best_i = take ? pi : best_i;
+      };
+      exchange(t_dpp<0xb1>(best_d), t_dpp<0xb1>(best_i), up1);    // pairs
+      exchange(t_dpp<0x1b>(best_d), t_dpp<0x1b>(best_i), up2);    // mirror within 4
+      exchange(t_dpp<0xb1>(best_d), t_dpp<0xb1>(best_i), up1);
+      exchange(t_dpp<0x141>(best_d), t_dpp<0x141>(best_i), up4);  // mirror within 8 (row_half_mirror)
+      exchange(t_dpp<0x4e>(best_d), t_dpp<0x4e>(best_i), up2);    // xor 2
+      exchange(t_dpp<0xb1>(best_d), t_dpp<0xb1>(best_i), up1);
+      exchange(t_dpp<0x140>(best_d), t_dpp<0x140>(best_i), up8);  // mirror within 16 (row_mirror)
+      exchange(t_xor4(best_d), t_xor4(best_i), up4);
+      exchange(t_dpp<0x4e>(best_d), t_dpp<0x4e>(best_i), up2);
+      exchange(t_dpp<0xb1>(best_d), t_dpp<0xb1>(best_i), up1);
+      const float w = __uint_as_float(t_lane_read(best_d, (team << 4) + a.k - 1));
+      tau2 = knn_gate_from_worst(w);
+      first_sorted = true;
+    }
     for (int base = 0; base < steps; base += 16) {
       const int j = base >> 4;
       const int32_t ecur = entry_reg(j), enext = entry_reg(j < 5 ? j + 1 : 5);
@@ -322,7 +369,7 @@ __device__ __forceinline__ void team_pass(const TeamArgs &a, const TeamLds &L, i
       const int end = min(base + 16, steps);
       for (int it = base; it < end; it += 2) {
         const LbvhPoint pb = load_block_point<HALO>(own_pts, halo_pts, entry_at(it + 1));
-        process(pa);
+        if (!(first_sorted && it == 0)) process(pa);
         if (it + 1 < end) {
           pa = load_block_point<HALO>(own_pts, halo_pts, entry_at(it + 2));
           process(pb);
