@@ -212,6 +212,22 @@ def main():
     if not sharded:
         line["build_ms"] = float(build_info["build_ms"])
         line["tree_bytes"] = int(build_info["device_bytes"])
+    if rank == 0:
+        # context for the roofline ("report against the measured stream peak as well"): a plain
+        # device-to-device copy of 1 GiB on this GPU, read + write bytes over the best of 5 timings
+        src = torch.empty(1 << 28, dtype=torch.float32, device=dev)
+        dst = torch.empty_like(src)
+        best = None
+        for _ in range(5):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            dst.copy_(src)
+            e1.record()
+            e1.synchronize()
+            t = e0.elapsed_time(e1)
+            best = t if best is None else min(best, t)
+        line["roofline"]["measured_copy_GBps"] = 2 * src.numel() * 4 / (best * 1e-3) / 1e9
+        del src, dst
     if rank == 0 and not sharded and not args.no_cpu_baseline:
         cb, ref, q = cpu_baseline(xyz_host, k, r0)
         line["cpu_baseline"] = cb
