@@ -175,6 +175,16 @@ typedef struct {
 } tknnDbscanInfo;
 TKNN_API int tknnDbscan(tknnEngine e, float eps, int min_pts, int32_t *d_labels, uint8_t *d_core,
                         int32_t *d_counts, tknnDbscanInfo *info, void *stream);
+/* Labels, core flags and counts are indexed by ROW (position of the point in the buffer given to
+ * tknnBuild / tknnBuildIds), also for engines built with ids; clusters are numbered by ascending
+ * smallest core row.
+ * tknnDbscanAssign: the last step alone, with labels decided by the caller (sharded use: labels
+ * agreed between tiles).  d_core_label[row] >= 0: the point is core and has that label; < 0: it is
+ * not core.  d_labels[row] = that label for core points, the smallest label among the core points
+ * within eps for the others, -1 if there is none.  Core points within eps of each other must carry
+ * the same label (true of any DBSCAN clustering). */
+TKNN_API int tknnDbscanAssign(tknnEngine e, float eps, const int32_t *d_core_label, int32_t *d_labels,
+                              tknnDbscanInfo *info, void *stream);
 
 /* Test / debug export of the tree to host memory (any pointer may be NULL):
  *   nodes      (n-1) x 8 dwords {lo[3], split, hi[3], other}   (include/owl/lbvh_device.h)

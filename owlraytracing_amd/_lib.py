@@ -93,6 +93,8 @@ SIGNATURES = {
                                        ctypes.c_void_p, ctypes.POINTER(ctypes.c_int64), ctypes.c_void_p]),
     "tknnDbscan": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_float, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
                                   ctypes.c_void_p, ctypes.POINTER(DbscanInfo), ctypes.c_void_p]),
+    "tknnDbscanAssign": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_float, ctypes.c_void_p, ctypes.c_void_p,
+                                        ctypes.POINTER(DbscanInfo), ctypes.c_void_p]),
     "tknnExportTree": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                                       ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     "tknnDebugThresholds": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64,

@@ -87,7 +87,7 @@ __device__ __forceinline__ void uf_unite(int32_t *parent, int32_t a, int32_t b) 
 }
 
 // Walks the tree for the CORE neighbours of q, tight nodes settled as a whole: calls
-// f(representative's id) for every tight node that has a core point within eps of q (its first core
+// f(representative's row) for every tight node that has a core point within eps of q (its first core
 // point stands for all of them) and for every core point within eps reached as a leaf.  `own_slot`
 // (or -1) names q's own sorted slot: the tight node holding it is skipped.
 template <typename F>
@@ -107,9 +107,9 @@ __device__ __forceinline__ void for_each_core_group(const DbArgs &a, const LbvhP
           float far2, near2;
           box_dist2(nd, q, far2, near2);
           if (far2 <= a.eps_in2) {
-            f(bvh.points[s].id);
+            f(bvh.prim_id[s]);
           } else if (near2 <= a.eps_out2) {
-            const int32_t rep_id = bvh.points[s].id;
+            const int32_t rep_id = bvh.prim_id[s];
             for (; s <= last; s = a.next_core[s + 1]) {
               const LbvhPoint p = bvh.points[s];
               if (knn_sqrt(knn_dist2(p.x, p.y, p.z, q.x, q.y, q.z)) <= a.eps) {
@@ -127,7 +127,7 @@ __device__ __forceinline__ void for_each_core_group(const DbArgs &a, const LbvhP
       const int32_t slot = ~ref;
       if (a.core_sorted[slot] && slot != own_slot) {
         const LbvhPoint p = bvh.points[slot];
-        if (knn_sqrt(knn_dist2(p.x, p.y, p.z, q.x, q.y, q.z)) <= a.eps) f(p.id);
+        if (knn_sqrt(knn_dist2(p.x, p.y, p.z, q.x, q.y, q.z)) <= a.eps) f(bvh.prim_id[slot]);
       }
       ref = bvh.rope_leaf[slot];
     }
@@ -170,9 +170,12 @@ __global__ void __launch_bounds__(kDbBlock) db_core_kernel(DbArgs a) {
   }
   const uint8_t is_core = cnt >= a.min_pts;
   a.core_sorted[t] = is_core;
-  if (a.core) a.core[q.id] = is_core;
-  if (a.counts) a.counts[q.id] = cnt;
-  a.parent[q.id] = q.id;
+  // results and the union-find are indexed by ROW (the point's position in the caller's buffer,
+  // prim_id of the sorted slot), not by the id an engine built with tknnBuildIds reports
+  const int32_t row = bvh.prim_id[t];
+  if (a.core) a.core[row] = is_core;
+  if (a.counts) a.counts[row] = cnt;
+  a.parent[row] = row;
 }
 
 // next_core[s] = first core slot >= s (n if none): with rank[s] = number of core slots before s (an
@@ -203,6 +206,7 @@ __global__ void __launch_bounds__(kDbBlock) db_union_kernel(DbArgs a) {
   if (t >= a.bvh.n || !a.core_sorted[t]) return;
   const LbvhView &bvh = a.bvh;
   const LbvhPoint q = bvh.points[t];
+  const int32_t row = bvh.prim_id[t];
   // the first tight node on my own root path: its core points are one cluster, held together by its
   // first core point
   int32_t node = bvh.root;
@@ -210,13 +214,13 @@ __global__ void __launch_bounds__(kDbBlock) db_union_kernel(DbArgs a) {
     const LbvhNode nd = bvh.nodes[node];
     if (node_is_tight(nd, a.eps_in2)) {
       const int32_t s = a.next_core[lbvh_first(node, nd.other)];  // <= t: I am core and inside
-      if (s != t) uf_unite(a.parent, q.id, bvh.points[s].id);
+      if (s != t) uf_unite(a.parent, row, bvh.prim_id[s]);
       break;
     }
     node = t <= nd.split ? lbvh_left_ref(node, nd) : lbvh_right_ref(node, nd);
   }
-  for_each_core_group(a, q, t, [&](int32_t id) {
-    if (id != q.id) uf_unite(a.parent, q.id, id);
+  for_each_core_group(a, q, t, [&](int32_t other) {
+    if (other != row) uf_unite(a.parent, row, other);
   });
 }
 
@@ -224,7 +228,7 @@ __global__ void __launch_bounds__(kDbBlock) db_union_kernel(DbArgs a) {
 __global__ void __launch_bounds__(kDbBlock) db_flatten_kernel(DbArgs a, int32_t *is_root) {
   const int32_t t = blockIdx.x * kDbBlock + threadIdx.x;
   if (t >= a.bvh.n) return;
-  const int32_t id = a.bvh.points[t].id;
+  const int32_t id = a.bvh.prim_id[t];
   int32_t flag = 0;
   if (a.core_sorted[t]) {
     const int32_t root = uf_find(a.parent, id);
@@ -238,22 +242,45 @@ __global__ void __launch_bounds__(kDbBlock) db_label_kernel(DbArgs a) {
   const int32_t t = blockIdx.x * kDbBlock + threadIdx.x;
   if (t >= a.bvh.n) return;
   const LbvhPoint q = a.bvh.points[t];
+  const int32_t row = a.bvh.prim_id[t];
   int32_t root = -1;
   if (a.core_sorted[t]) {
-    root = uf_find(a.parent, q.id);
+    root = uf_find(a.parent, row);
   } else {
-    for_each_core_group(a, q, -1, [&](int32_t id) {
-      const int32_t r = uf_find(a.parent, id);
+    for_each_core_group(a, q, -1, [&](int32_t other) {
+      const int32_t r = uf_find(a.parent, other);
       if (root < 0 || r < root) root = r;
     });
   }
-  a.labels[q.id] = root < 0 ? -1 : a.rank[root];
+  a.labels[row] = root < 0 ? -1 : a.rank[root];
+}
+
+// tknnDbscanAssign: the caller has decided the label of every core point (>= 0; < 0: not core); a
+// core point keeps it, any other point takes the smallest label among its core neighbours, or -1
+__global__ void __launch_bounds__(kDbBlock) db_core_from_labels_kernel(DbArgs a, const int32_t *core_label) {
+  const int32_t t = blockIdx.x * kDbBlock + threadIdx.x;
+  if (t < a.bvh.n) a.core_sorted[t] = core_label[a.bvh.prim_id[t]] >= 0;
+}
+__global__ void __launch_bounds__(kDbBlock) db_assign_kernel(DbArgs a, const int32_t *core_label) {
+  const int32_t t = blockIdx.x * kDbBlock + threadIdx.x;
+  if (t >= a.bvh.n) return;
+  const LbvhPoint q = a.bvh.points[t];
+  const int32_t row = a.bvh.prim_id[t];
+  int32_t best = core_label[row];
+  if (best < 0) {
+    best = -1;
+    for_each_core_group(a, q, -1, [&](int32_t other) {
+      const int32_t l = core_label[other];  // a tight node's core points share one label: its first stands for all
+      if (best < 0 || l < best) best = l;
+    });
+  }
+  a.labels[row] = best;
 }
 
 }  // namespace
 
 void Engine::dbscan(float eps, int min_pts, int32_t *d_labels, uint8_t *d_core, int32_t *d_counts,
-                    tknnDbscanInfo *info, hipStream_t s) {
+                    tknnDbscanInfo *info, hipStream_t s, const int32_t *core_label) {
   const int64_t n = bvh_.size();
   // scratch: core flags per slot, parent, root flags, ranks
   const size_t need = (((size_t)n * (1 + 4 + 4 + 4 + 4)) + 16 + 255) / 256 * 256;  // + next_core, + two sentinels
@@ -287,7 +314,11 @@ void Engine::dbscan(float eps, int min_pts, int32_t *d_labels, uint8_t *d_core, 
   const unsigned blocks = (unsigned)((n + kDbBlock - 1) / kDbBlock);
   hipEvent_t e0 = ev_a_, e1 = ev_b_;
   OWLMI_HIP(hipEventRecord(e0, s));
-  hipLaunchKernelGGL(db_core_kernel, dim3(blocks), dim3(kDbBlock), 0, s, a);
+  if (core_label) {
+    hipLaunchKernelGGL(db_core_from_labels_kernel, dim3(blocks), dim3(kDbBlock), 0, s, a, core_label);
+  } else {
+    hipLaunchKernelGGL(db_core_kernel, dim3(blocks), dim3(kDbBlock), 0, s, a);
+  }
   {
     // next_core: flags -> exclusive sum (rank of a slot among the core slots) -> slot of the r-th core
     // point -> first core slot at or after each slot.  is_root / rank are free until the unions are done.
@@ -298,6 +329,19 @@ void Engine::dbscan(float eps, int min_pts, int32_t *d_labels, uint8_t *d_core, 
     OWLMI_HIP(hipMemsetAsync(pos, 0x7f, ((size_t)n + 1) * sizeof(int32_t), s));  // 0x7f7f7f7f: "none", clamped below
     hipLaunchKernelGGL(db_core_pos_kernel, dim3(blocks), dim3(kDbBlock), 0, s, a, core_rank, pos);
     hipLaunchKernelGGL(db_next_core_kernel, dim3(blocks1), dim3(kDbBlock), 0, s, a, core_rank, pos, next_core);
+  }
+  if (core_label) {
+    hipLaunchKernelGGL(db_assign_kernel, dim3(blocks), dim3(kDbBlock), 0, s, a, core_label);
+    OWLMI_HIP(hipGetLastError());
+    OWLMI_HIP(hipEventRecord(e1, s));
+    OWLMI_HIP(hipStreamSynchronize(s));
+    if (info) {
+      float ms = 0;
+      OWLMI_HIP(hipEventElapsedTime(&ms, e0, e1));
+      info->clusters = -1;
+      info->solve_ms = ms;
+    }
+    return;
   }
   hipLaunchKernelGGL(db_union_kernel, dim3(blocks), dim3(kDbBlock), 0, s, a);
   hipLaunchKernelGGL(db_flatten_kernel, dim3(blocks), dim3(kDbBlock), 0, s, a, is_root);

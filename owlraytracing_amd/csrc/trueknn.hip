@@ -676,6 +676,19 @@ int tknnDbscan(tknnEngine e, float eps, int min_pts, int32_t *d_labels, uint8_t 
   });
 }
 
+int tknnDbscanAssign(tknnEngine e, float eps, const int32_t *d_core_label, int32_t *d_labels, tknnDbscanInfo *info,
+                     void *stream) {
+  if (!e || !d_labels || !d_core_label) {
+    g_last_error = "tknnDbscanAssign: engine, core labels or labels pointer is NULL";
+    return TKNN_E_ARG;
+  }
+  return guarded([&] {
+    if (!e->impl.built()) throw owlmi::ArgError{TKNN_E_STATE, "tknnDbscanAssign: call tknnBuild first"};
+    if (!(eps > 0.f) || !std::isfinite(eps)) throw owlmi::ArgError{TKNN_E_ARG, "tknnDbscanAssign: eps must be finite and > 0"};
+    e->impl.dbscan(eps, 1, d_labels, nullptr, nullptr, info, (hipStream_t)stream, d_core_label);
+  });
+}
+
 int tknnExportTree(tknnEngine e, void *nodes, int32_t *rope_node, int32_t *rope_leaf, int32_t *prim_id,
                    void *stream) {
   if (!e) {

@@ -52,8 +52,10 @@ class Engine {
   void solve(const SolveArgs &sa, int kernel, tknnSolveInfo *info, hipStream_t s);
   // rewrites the rows whose k-th distance exceeds their final box half-width with exact kNN; returns how many
   int64_t repair_exact(int k, float start_radius, const int32_t *d_levels, int32_t *d_idx, float *d_dist, hipStream_t s);
+  // dbscan.hip; with core_label (per row: the label the caller gave each core point, < 0 for others) only
+  // the assignment runs: core points keep their label, others take the smallest among their core neighbours
   void dbscan(float eps, int min_pts, int32_t *d_labels, uint8_t *d_core, int32_t *d_counts, tknnDbscanInfo *info,
-              hipStream_t s);  // dbscan.hip
+              hipStream_t s, const int32_t *core_label = nullptr);
   bool built() const { return bvh_.built(); }
   int64_t size() const { return bvh_.size(); }
   const Lbvh &tree() const { return bvh_; }

@@ -109,6 +109,8 @@ class ShardedTrueKNN:
             from .trueknn import TrueKNN
             engine_factory = lambda dev: TrueKNN(device=dev.index)  # noqa: E731
         self.engine = engine_factory(self.device)
+        self._engine_factory = engine_factory
+        self.db_engine = None   # second engine over own + halo points (dbscan)
         # first halo radius = start_radius * 2**halo_levels; None: from the density of the set, the level
         # at which a box is expected to hold 32 k points (nearly every query has finished by then, so
         # one exchange and one solve do; stragglers still widen the halo and go again)
@@ -324,6 +326,82 @@ class ShardedTrueKNN:
         self.last = res
         self.last["info"] = info
         return info
+
+    # ---- RT-DBSCAN over the tiles (last row) -----------------------------------
+    def dbscan(self, eps, min_pts):
+        """DBSCAN of the whole set with the single-GPU spec (oracle/dbscan_oracle.c): returns
+        dict(labels (m,) int32, core (m,) bool) for the points this rank owns (``self.ids`` order) and
+        info(clusters, rounds, halo_points).  Clusters are numbered by ascending smallest core id, so
+        the labels equal a single-process run over the union.
+
+        Each rank clusters its tile plus a halo of radius 2 eps: core flags are then exact for its own
+        points and for every foreign point that can be their neighbour, and every edge of the
+        neighbour graph is seen by a rank owning one of its ends.  Components are merged by label
+        propagation: label = smallest core id known for the component; a round takes the minimum
+        over each local component, sends the labels of halo copies back to their owners (minimum) and
+        the owners' labels out to the copies again, until nothing changes anywhere."""
+        comm, dev = self.comm, self.device
+        eps32 = float(np.float32(eps))
+        m = len(self.points)
+        blocks = self._halo_blocks(2.0 * eps32)
+        got = comm.exchange_rows(blocks, 4, torch.float32, dev)
+        got[comm.rank] = got[comm.rank][:0]
+        counts_in = [len(g) for g in got]
+        halo = torch.cat(got, dim=0)
+        # the rows I sent, as positions in my own arrays (values travel in the same order later)
+        id_sorted, id_perm = torch.sort(self.ids.long())
+        sent_local = [id_perm[torch.searchsorted(id_sorted, b[:, 3].contiguous().view(torch.int32).long())]
+                      if len(b) else torch.zeros(0, dtype=torch.long, device=dev) for b in blocks]
+        pts = torch.cat([self.points, halo[:, :3]], dim=0).contiguous()
+        ids = torch.cat([self.ids, halo[:, 3].contiguous().view(torch.int32)], dim=0).contiguous()
+        if self.db_engine is None:
+            self.db_engine = self._engine_factory(dev)
+        self.db_engine.build(pts, ids)
+        local = self.db_engine.dbscan(eps32, min_pts)
+        core = local["core"].to(dev).bool()
+        comp = local["labels"].to(dev).long()
+        big = torch.iinfo(torch.int64).max
+        lab = torch.where(core, ids.long(), torch.full_like(ids, big, dtype=torch.int64))
+        ncomp = int(comp[core].max().item()) + 1 if bool(core.any()) else 0
+        core_idx = torch.nonzero(core).flatten()
+        rounds = 0
+        while True:
+            rounds += 1
+            before = lab[:m].clone()
+            if ncomp:
+                cmin = torch.full((ncomp,), big, dtype=torch.int64, device=dev)
+                cmin.scatter_reduce_(0, comp[core_idx], lab[core_idx], "amin")
+                lab[core_idx] = cmin[comp[core_idx]]
+            # copies -> owners (minimum)
+            offs = np.concatenate([[0], np.cumsum(counts_in)])
+            back = [lab[m + int(offs[s]): m + int(offs[s + 1])].reshape(-1, 1).contiguous() for s in range(comm.world)]
+            for p, vals in enumerate(comm.exchange_rows(back, 1, torch.int64, dev)):
+                if p != comm.rank and len(vals):
+                    lab[:m].scatter_reduce_(0, sent_local[p], vals.flatten(), "amin")
+            # owners -> copies
+            fwd = [lab[:m][sent_local[p]].reshape(-1, 1).contiguous() for p in range(comm.world)]
+            new = comm.exchange_rows(fwd, 1, torch.int64, dev)
+            new[comm.rank] = new[comm.rank][:0]
+            if len(halo):
+                lab[m:] = torch.cat(new, dim=0).flatten()
+            changed = torch.tensor([int(bool((lab[:m] != before).any()))], dtype=torch.int64, device=dev)
+            comm.all_reduce(changed, dist.ReduceOp.MAX)
+            if int(changed.item()) == 0:
+                break
+        # cluster numbers: ascending smallest core id over ALL ranks
+        mine = torch.unique(lab[:m][core[:m]])
+        width = torch.tensor([len(mine)], dtype=torch.int64, device=dev)
+        comm.all_reduce(width, dist.ReduceOp.MAX)
+        padded = torch.full((max(int(width.item()), 1),), big, dtype=torch.int64, device=dev)
+        padded[: len(mine)] = mine
+        everyone = torch.unique(comm.all_gather(padded).flatten())
+        everyone = everyone[everyone != big]
+        number = torch.searchsorted(everyone, lab.clamp(max=int(everyone[-1].item()) if len(everyone) else 0))
+        known = core & (lab != big)
+        core_label = torch.where(known, number, torch.full_like(number, -1)).int()
+        labels = self.db_engine.dbscan_assign(eps32, core_label)
+        info = {"clusters": int(len(everyone)), "rounds": rounds, "halo_points": int(len(halo))}
+        return {"labels": labels[:m].to(dev), "core": core[:m], "info": info}
 
     def gather_rows(self):
         """(global_ids, idx, dist, intersections) of every rank concatenated on every rank (tests)."""

@@ -182,6 +182,21 @@ class TrueKNN:
             out["counts"] = counts
         return out
 
+    def dbscan_assign(self, eps, core_label):
+        """Last step of DBSCAN with labels decided by the caller: ``core_label`` (n,) int32, >= 0 for
+        core points.  Returns labels (n,) int32: core points keep theirs, the others take the smallest
+        label among the core points within eps, -1 if there is none."""
+        torch = self._torch
+        with torch.cuda.device(self.device):
+            core_label = torch.as_tensor(core_label, dtype=torch.int32, device=self.device).contiguous()
+            if core_label.shape != (self.n,):
+                raise ValueError("core_label must have one entry per point")
+            labels = torch.empty((self.n,), dtype=torch.int32, device=self.device)
+            info = _lib.DbscanInfo()
+            _lib.check(self._lib.tknnDbscanAssign(self._h, ctypes.c_float(eps), ctypes.c_void_p(core_label.data_ptr()),
+                                                  ctypes.c_void_p(labels.data_ptr()), ctypes.byref(info), self._stream()))
+        return labels
+
     def export_tree(self):
         """Host copies of the LBVH for tests: nodes (n-1,8) uint32 view, ropes, prim ids."""
         torch = self._torch

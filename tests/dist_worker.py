@@ -51,6 +51,31 @@ class CheckerEngine:
                 "levels": torch.from_numpy(lev.astype(np.int32)), "info": info}
 
 
+    # ---- DBSCAN: the CPU spec (oracle/dbscan_oracle.c) behind the same two calls as the HIP engine ----
+    def dbscan(self, eps, min_pts, want_counts=False):
+        import oracle
+        r = oracle.dbscan(self.pts, eps, min_pts)
+        return {"labels": torch.from_numpy(r["labels"].astype(np.int32)), "core": torch.from_numpy(r["core"].astype(bool)),
+                "info": {"clusters": int(r["clusters"])}}
+
+    def dbscan_assign(self, eps, core_label):
+        from scipy.spatial import cKDTree
+        lab = np.asarray(core_label.cpu().numpy(), np.int32)
+        out = lab.copy()
+        tree = cKDTree(self.pts.astype(np.float64))
+        eps = np.float32(eps)
+        for q in np.nonzero(lab < 0)[0]:
+            best = -1
+            for p in tree.query_ball_point(self.pts[q].astype(np.float64), float(eps) * 1.0001 + 1e-30):
+                if lab[p] < 0:
+                    continue
+                d = self.pts[p] - self.pts[q]
+                if np.sqrt((d[0] * d[0] + d[1] * d[1]) + d[2] * d[2], dtype=np.float32) <= eps and (best < 0 or lab[p] < best):
+                    best = lab[p]
+            out[q] = best
+        return torch.from_numpy(out)
+
+
 def make_points(name, n):
     if name == "uniform":
         return datasets.uniform3d(n, seed=5)
@@ -73,6 +98,20 @@ def main():
     lo, hi = n * rank // world, n * (rank + 1) // world  # arbitrary initial ownership: contiguous slices
     solver = tkd.ShardedTrueKNN(dev, engine_factory=None if use_gpu else CheckerEngine, halo_levels=int(os.environ.get("HALO_LEVELS", "1")))
     solver.load_points(torch.from_numpy(pts[lo:hi]), torch.arange(lo, hi, dtype=torch.int32))
+    if os.environ.get("DBSCAN_EPS"):
+        r = solver.dbscan(float(os.environ["DBSCAN_EPS"]), int(os.environ.get("DBSCAN_MINPTS", "4")))
+        rows = torch.cat([solver.ids.view(-1, 1).double().cpu(), r["labels"].view(-1, 1).double().cpu(),
+                          r["core"].view(-1, 1).double().cpu()], dim=1).to(dev)
+        got = torch.cat(solver.comm.exchange_rows([rows for _ in range(world)], 3, torch.float64, dev), dim=0).cpu().numpy()
+        got = got[np.argsort(got[:, 0])]
+        print("rank %d tile=%d halo=%d clusters=%d label rounds=%d" % (rank, len(solver.points), r["info"]["halo_points"],
+                                                                    r["info"]["clusters"], r["info"]["rounds"]), flush=True)
+        if rank == 0:
+            np.savez(out, gids=got[:, 0].astype(np.int64), labels=got[:, 1].astype(np.int32), core=got[:, 2].astype(bool),
+                     clusters=r["info"]["clusters"])
+        dist.barrier()
+        dist.destroy_process_group()
+        return
     r0 = float(os.environ.get("START_RADIUS", datasets.start_radius(n, k)))
     import time
     t0 = time.perf_counter()

@@ -71,6 +71,32 @@ def test_four_ranks_sharing_one_gpu_cross_z_curve_jumps(tmp_path):
     assert int(got["halo_points"]) < int(got["tile"]) // 2
 
 
+def _check_dbscan(got, name, n, eps, min_pts):
+    from dist_worker import make_points
+    ref = oracle.dbscan(make_points(name, n), eps, min_pts)
+    assert np.array_equal(got["gids"], np.arange(n))
+    assert np.array_equal(got["core"], ref["core"].astype(bool))
+    assert int(got["clusters"]) == int(ref["clusters"])
+    assert np.array_equal(got["labels"], ref["labels"])
+
+
+@pytest.mark.parametrize("world,name,n,eps,min_pts", [(2, "clustered", 6000, 0.02, 5), (3, "uniform", 5000, 0.035, 4),
+                                                     (3, "planar", 6000, 0.004, 6)])
+def test_sharded_dbscan_equals_the_single_process_spec(tmp_path, world, name, n, eps, min_pts):
+    """Tiles + 2-eps halo + label propagation between ranks (gloo, CPU stand-in engine running the
+    spec per tile): labels, core flags and cluster count equal oracle.dbscan over the whole set."""
+    eps = float(np.float32(eps))
+    got = _run("checker", world, n, 4, name, tmp_path, 29660 + world, {"DBSCAN_EPS": repr(eps), "DBSCAN_MINPTS": str(min_pts)})
+    _check_dbscan(got, name, n, eps, min_pts)
+
+
+@pytest.mark.gpu
+def test_sharded_dbscan_with_the_hip_engine(tmp_path):
+    n, eps, min_pts = 300_000, float(np.float32(0.012)), 5
+    got = _run("hip", 3, n, 4, "clustered", tmp_path, 29671, {"DBSCAN_EPS": repr(eps), "DBSCAN_MINPTS": str(min_pts)})
+    _check_dbscan(got, "clustered", n, eps, min_pts)
+
+
 @pytest.mark.gpu
 def test_halo_select_matches_a_plain_selection():
     """tknnHaloSelect (send side of the exchange): per peer, exactly the points inside any of its boxes,
