@@ -491,7 +491,7 @@ void Engine::solve(const SolveArgs &sa, int kernel, tknnSolveInfo *info, hipStre
   }
   if (kernel == TKNN_KERNEL_TEAM) {
     if (solve_team(sa, info, s)) return;
-    kernel = TKNN_KERNEL_WAVE;  // candidate sets too large for the team kernel's block masks
+    kernel = TKNN_KERNEL_WAVE;  // (solve_team handles its own tail and returns true today)
   }
   if (kernel == TKNN_KERNEL_WAVE)
     solve_wave(sa, info, s);

@@ -490,7 +490,7 @@ __global__ void __launch_bounds__(kTeamBlock) __attribute__((amdgpu_waves_per_eu
 
     for (;;) {  // radius levels
       PHASE_END(4);
-      // ---- 1. thresholds, query records ----------------------------------------------------
+      // ---- 1. query records, conservative query boxes ---------------------------------------
       // This step serves levels level .. level+m-1 with ONE gather at the outermost radius.
       int m = step < 1 ? 1 : (step > kMaxStep ? kMaxStep : step);
       if (level + m > a.max_rounds) m = a.max_rounds - level;
@@ -890,7 +890,7 @@ bool Engine::solve_team(const SolveArgs &sa, tknnSolveInfo *info, hipStream_t s)
             (double)wave_steps, (double)h_counters_[3] / LBVH_BLOCK, 100.0 * ((double)h_counters_[3] / LBVH_BLOCK) / (4.0 * (double)wave_steps));
     fprintf(stderr, "[team diag] mean busy time per wave %.2f ms of %.2f ms kernel time (%d waves; s_memtime at 100 MHz)\n",
             tot / 1e8 * 1e3 / blocks, ms, blocks);
-    fprintf(stderr, "[team diag] wave-time shares: thresholds %.1f%%  gather %.1f%%  count %.1f%%  select %.1f%%  rest %.1f%%\n",
+    fprintf(stderr, "[team diag] wave-time shares: records %.1f%%  gather %.1f%%  count %.1f%%  select %.1f%%  rest %.1f%%\n",
             100 * t[0] / tot, 100 * t[1] / tot, 100 * t[2] / tot, 100 * t[3] / tot, 100 * t[4] / tot);
   }
 #endif

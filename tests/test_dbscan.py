@@ -114,3 +114,38 @@ def test_hip_dbscan_argument_errors():
         with pytest.raises(_lib.TknnError):
             eng.dbscan(eps, m)
     eng.close()
+
+
+@pytest.mark.gpu
+def test_hip_dbscan_rows_not_ids_and_the_assign_step():
+    """An engine built with ids (sharded use) still indexes DBSCAN results by row, and
+    tknnDbscanAssign reproduces the last step from caller-decided core labels."""
+    import torch
+
+    from owlraytracing_amd.trueknn import TrueKNN
+    xyz = datasets.gaussian_mixture3d(30_000, components=5, sigma=0.03, seed=9)
+    eps, min_pts = float(np.float32(0.015)), 6
+    ref = oracle.dbscan(xyz, eps, min_pts)
+    eng = TrueKNN()
+    ids = (np.arange(len(xyz), dtype=np.int32)[::-1] * 7 + 1_000_000).copy()  # far outside 0..n-1
+    eng.build(torch.from_numpy(xyz).cuda(), torch.from_numpy(ids).cuda())
+    got = eng.dbscan(eps, min_pts)
+    assert np.array_equal(got["core"].cpu().numpy(), ref["core"].astype(bool))
+    assert np.array_equal(got["labels"].cpu().numpy(), ref["labels"])
+    # relabel the clusters arbitrarily (order-reversing), hand in core labels only, get everything back
+    ncl = int(ref["clusters"])
+    remap = np.arange(ncl, dtype=np.int32)[::-1] * 3 + 5
+    core_label = np.where(ref["core"].astype(bool), remap[np.maximum(ref["labels"], 0)], -1).astype(np.int32)
+    out = eng.dbscan_assign(eps, torch.from_numpy(core_label).cuda()).cpu().numpy()
+    core = ref["core"].astype(bool)
+    assert np.array_equal(out[core], core_label[core])
+    from scipy.spatial import cKDTree
+    tree = cKDTree(xyz.astype(np.float64))
+    for q in np.nonzero(~core)[0][:400]:
+        want = -1
+        for p in tree.query_ball_point(xyz[q].astype(np.float64), eps * 1.0001):
+            d = xyz[p] - xyz[q]
+            if core[p] and np.sqrt((d[0] * d[0] + d[1] * d[1]) + d[2] * d[2], dtype=np.float32) <= np.float32(eps):
+                want = core_label[p] if want < 0 else min(want, core_label[p])
+        assert out[q] == want
+    eng.close()

@@ -32,7 +32,8 @@ def test_golden_vectors(golden, kernel):
             eng.solve(k, float(golden["start_radius"]), kernel=kernel)
         return
     r = eng.solve(k, float(golden["start_radius"]), kernel=kernel, want_fb=True)
-    # the team kernel hands packets whose candidate sets outgrow its block masks to the wave kernel
+    # (the team kernel finishes packets whose candidate sets outgrow its lists with lane rounds or the
+    # wave kernel and still reports itself)
     assert r["info"]["kernel_used"] in ((kernel, _lib.KERNEL_WAVE) if kernel == _lib.KERNEL_TEAM else (kernel,))
     assert r["info"]["rounds"] == int(golden["rounds"])
     assert np.float32(r["info"]["final_radius"]) == golden["final_radius"]
