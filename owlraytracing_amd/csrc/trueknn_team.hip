@@ -182,10 +182,19 @@ __device__ __forceinline__ float t_dist2(float dx, float dy, float dz) {
 // one leaf block = LBVH_BLOCK sorted points, 16 bytes each; lane tl of a team reads point tl.
 // The sorted arrays are padded with NaN sentinels to whole blocks and followed by one all-NaN block
 // (lbvh.hip), so there is no bounds test and "no block" is an ordinary entry.
+// Without a halo tree an entry is resolved to the block's BYTE offset when the entry registers are
+// filled, and the load is "uniform base + 32-bit lane offset" (saddr form): one add per block
+// instead of a mask, a 64-bit shift and a 64-bit add.  (Blocks < 2^24, i.e. n < 2^28: solve_team checks.)
 template <bool HALO>
-__device__ __forceinline__ LbvhPoint load_block_point(const LbvhPoint *own, const LbvhPoint *halo, int32_t entry) {
-  const LbvhPoint *base = (HALO && entry < 0) ? halo : own;
+__device__ __forceinline__ LbvhPoint load_block_point(const LbvhPoint *own, const LbvhPoint *halo, int32_t entry,
+                                                      const LbvhPoint *own_base, uint32_t lane_bytes) {
+  if (!HALO) return *(const LbvhPoint *)((const char *)own_base + ((uint32_t)entry + lane_bytes));
+  const LbvhPoint *base = entry < 0 ? halo : own;
   return base[(int64_t)(entry & 0x7fffffff) * LBVH_BLOCK];
+}
+template <bool HALO>
+__device__ __forceinline__ int32_t resolve_entry(int32_t e) {
+  return HALO ? e : (int32_t)((uint32_t)e * (uint32_t)(LBVH_BLOCK * sizeof(LbvhPoint)));
 }
 
 struct TeamLds {
@@ -231,7 +240,8 @@ __device__ __forceinline__ void team_pass(const TeamArgs &a, const TeamLds &L, i
     // the own tree's last block: its points fail every test, so the loop needs no "am I still in
     // my list" check
     const int32_t nan_block = a.wide[0].count[0];
-    int32_t e0 = nan_block, e1 = nan_block, e2 = nan_block, e3 = nan_block, e4 = nan_block, e5 = nan_block;  // named, not an array: must stay in VGPRs
+    const int32_t nan_entry = resolve_entry<HALO>(nan_block);
+    int32_t e0 = nan_entry, e1 = nan_entry, e2 = nan_entry, e3 = nan_entry, e4 = nan_entry, e5 = nan_entry;  // named, not an array: must stay in VGPRs
     // SELECT visits blocks outward from the query's own block, alternating sides of its Morton-ordered
     // list: near blocks first tightens the k-th-distance gate early (about 30 % fewer inserts than
     // list order on uniform data) and changes nothing else -- the result does not depend on order.
@@ -251,7 +261,7 @@ __device__ __forceinline__ void team_pass(const TeamArgs &a, const TeamLds &L, i
     auto list_entry = [&](int pos) -> int32_t {
       const int at = min(max(list_pos(pos), 0), kMaxPerQuery - 1);
       const int32_t e = L.blk[mine[at]];
-      return pos <= last ? e : nan_block;
+      return resolve_entry<HALO>(pos <= last ? e : nan_block);
     };
     e0 = list_entry(tl);
     if (steps > 16) e1 = list_entry(tl + 16);
@@ -284,8 +294,9 @@ __device__ __forceinline__ void team_pass(const TeamArgs &a, const TeamLds &L, i
       }
       if (SELECT) {
         const float d2 = t_dist2(dx, dy, dz);
-        // candidates other than the query itself (ids are unique) that pass the gate
-        unsigned long long pm = in_m & __ballot(p.id != t_qid) & __ballot(d2 <= tau2);
+        // candidates that pass the gate.  The query itself sits in its own block, which SELECT visits
+        // first and settles in the sorted first step, so no block seen here can hold it (ids are unique).
+        unsigned long long pm = in_m & __ballot(d2 <= tau2);
         if (TKNN_DIAG_BUILD && (a.diag & 1)) pm = 0;
         if (pm) {
           // exact key of my candidate, then one team-parallel sorted insert per pending lane
@@ -319,7 +330,9 @@ __device__ __forceinline__ void team_pass(const TeamArgs &a, const TeamLds &L, i
     // name some valid block, see above).  The list is walked in chunks of 16 entries = one entry
     // register, so picking the register (a scalar branch chain) happens once per chunk and an
     // entry costs one select + one cross-lane read.
-    LbvhPoint pa = load_block_point<HALO>(own_pts, halo_pts, (int32_t)t_lane_read((uint32_t)e0, team << 4));
+    const LbvhPoint *own_base = a.bvh.points;  // wave-uniform
+    const uint32_t lane_bytes = (uint32_t)tl * (uint32_t)sizeof(LbvhPoint);
+    LbvhPoint pa = load_block_point<HALO>(own_pts, halo_pts, (int32_t)t_lane_read((uint32_t)e0, team << 4), own_base, lane_bytes);
     bool first_sorted = false;
     if (SELECT && steps > 0) {
       // The first block (the query's own) meets an empty list: every candidate in it would be inserted,
@@ -368,10 +381,10 @@ __device__ __forceinline__ void team_pass(const TeamArgs &a, const TeamLds &L, i
       };
       const int end = min(base + 16, steps);
       for (int it = base; it < end; it += 2) {
-        const LbvhPoint pb = load_block_point<HALO>(own_pts, halo_pts, entry_at(it + 1));
+        const LbvhPoint pb = load_block_point<HALO>(own_pts, halo_pts, entry_at(it + 1), own_base, lane_bytes);
         if (!(first_sorted && it == 0)) process(pa);
         if (it + 1 < end) {
-          pa = load_block_point<HALO>(own_pts, halo_pts, entry_at(it + 2));
+          pa = load_block_point<HALO>(own_pts, halo_pts, entry_at(it + 2), own_base, lane_bytes);
           process(pb);
         }
       }
@@ -827,6 +840,7 @@ int Engine::first_step_estimate(const SolveArgs &sa) const {
 
 bool Engine::solve_team(const SolveArgs &sa, tknnSolveInfo *info, hipStream_t s) {
   const int64_t n = bvh_.size();
+  if (n >= (1ll << 28)) return false;  // leaf blocks are addressed by 32-bit byte offsets; the caller takes the wave kernel
   TeamArgs a;
   a.bvh = bvh_.view();
   a.halo = halo_view();
