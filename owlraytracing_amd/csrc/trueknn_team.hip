@@ -445,6 +445,7 @@ __global__ void __launch_bounds__(kTeamBlock) __attribute__((amdgpu_waves_per_eu
   unsigned long long my_isect_sum = 0, my_levels = 0, my_unfinished = 0, wave_node_tests = 0, wave_point_tests = 0;
   int wave_levels = 0, wave_err = 0;
   unsigned long long my_handed = 0;
+  [[maybe_unused]] unsigned long long diag_scanned = 0, diag_listed = 0;  // TKNN_DIAG_BUILD only
   int wave_min_handover = 0x7fffffff;
 #if TKNN_DIAG_BUILD
   unsigned long long ph[5] = {0, 0, 0, 0, 0}, t_mark = __builtin_amdgcn_s_memtime();
@@ -640,6 +641,7 @@ __global__ void __launch_bounds__(kTeamBlock) __attribute__((amdgpu_waves_per_eu
             // whole clusters none of its queries needs: testing those blocks one by one would keep
             // this wave busy long after the others have finished.  The lane kernel walks per query.
             scanned += __popcll(om);
+            if (TKNN_DIAG_BUILD && (a.diag & 32)) diag_scanned += __popcll(om);
             if (scanned > kScanBudget) {
               too_big = true;
               break;
@@ -685,6 +687,7 @@ __global__ void __launch_bounds__(kTeamBlock) __attribute__((amdgpu_waves_per_eu
         active = false;
         break;
       }
+      if (TKNN_DIAG_BUILD && (a.diag & 32)) diag_listed += nb;
       const int my_packed = my_nblk | (my_own_pos << 8);  // read back by the teams
       qrec[lane * kQrecStride + 7] = __int_as_float(my_packed);
 
@@ -818,6 +821,10 @@ __global__ void __launch_bounds__(kTeamBlock) __attribute__((amdgpu_waves_per_eu
     if (wave_err) atomicOr(&a.counters[5], (unsigned long long)wave_err);
 #if TKNN_DIAG_BUILD
     for (int i = 0; i < 5; i++) atomicAdd(&a.counters[10 + i], ph[i]);
+    if (a.diag & 32) {
+      atomicAdd(&a.counters[24], diag_scanned);
+      atomicAdd(&a.counters[25], diag_listed);
+    }
 #endif
   }
 }
@@ -902,6 +909,11 @@ bool Engine::solve_team(const SolveArgs &sa, tknnSolveInfo *info, hipStream_t s)
     OWLMI_HIP(hipMemcpy(&wave_steps, counters_ + 15, sizeof wave_steps, hipMemcpyDeviceToHost));
     fprintf(stderr, "[team diag] block steps: %.3g wave steps x 4 teams for %.3g listed blocks (lockstep efficiency %.1f%%)\n",
             (double)wave_steps, (double)h_counters_[3] / LBVH_BLOCK, 100.0 * ((double)h_counters_[3] / LBVH_BLOCK) / (4.0 * (double)wave_steps));
+    if (a.diag & 32) {
+      unsigned long long g[2];
+      OWLMI_HIP(hipMemcpy(g, counters_ + 24, sizeof g, hipMemcpyDeviceToHost));
+      fprintf(stderr, "[team diag] gather: %.3g leaf blocks tested against the 64 queries, %.3g of them listed (%.1f%%)\n", (double)g[0], (double)g[1], 100.0 * (double)g[1] / (double)g[0]);
+    }
     fprintf(stderr, "[team diag] mean busy time per wave %.2f ms of %.2f ms kernel time (%d waves; s_memtime at 100 MHz)\n",
             tot / 1e8 * 1e3 / blocks, ms, blocks);
     fprintf(stderr, "[team diag] wave-time shares: records %.1f%%  gather %.1f%%  count %.1f%%  select %.1f%%  rest %.1f%%\n",
