@@ -1,4 +1,4 @@
-// trueknn_team.hip -- the team TrueKNN kernel (TKNN_KERNEL_TEAM), k <= 16.
+// trueknn_team.hip -- the team TrueKNN kernel (TKNN_KERNEL_TEAM), k <= 32 (k > 16: two list registers per lane).
 //
 // The wave-packet kernel (trueknn_wave.hip) broadcasts every candidate of a 64-query packet to all
 // 64 lanes; on MI355X it is VALU-issue-bound with ~2.5 % useful lanes (profiles/r01_wave_v2_*),
@@ -208,7 +208,8 @@ struct TeamLds {
 // One pass of the four teams over a compact list of queries.  SELECT = false: count candidates
 // (deviceCode.cu:74,103).  SELECT = true: also keep the k best (dist,index) keys, lane j of the
 // team holding the j-th, and write the row if the query turns out finished (>= k others).
-template <bool SELECT, bool HALO>
+// NREG: list registers per lane -- the team's sorted list holds 16 * NREG keys (k <= 16: 1, k <= 32: 2)
+template <bool SELECT, bool HALO, int NREG>
 __device__ __forceinline__ void team_pass(const TeamArgs &a, const TeamLds &L, int n_list, float r_inner, int m,
                                           const LbvhPoint *own_pts, const LbvhPoint *halo_pts, int lane) {
   const int team = lane >> 4, tl = lane & 15;
@@ -274,6 +275,12 @@ __device__ __forceinline__ void team_pass(const TeamArgs &a, const TeamLds &L, i
     };
     uint32_t cnt = 0;
     uint32_t best_d = 0x7f7fffffu, best_i = 0u;  // KNN_EMPTY_KEY = {FLT_MAX, 0}
+    uint32_t best_d1 = 0x7f7fffffu, best_i1 = 0u;  // entries 16..31 (NREG == 2)
+    // the k-th best of my team, whose distance gates further candidates
+    auto kth_dist = [&]() -> float {
+      const uint32_t reg = (NREG > 1 && a.k > 16) ? best_d1 : best_d;
+      return __uint_as_float(t_lane_read(reg, (team << 4) + ((a.k - 1) & 15)));
+    };
     float tau2 = INFINITY;
     // one block's test; `it` is wave-uniform
     // Lane predicates are kept as 64-bit wave masks (SGPR pairs) from the compare to the branch: a
@@ -315,13 +322,26 @@ __device__ __forceinline__ void team_pass(const TeamArgs &a, const TeamLds &L, i
             const bool take_prev = has & (tl != 0) & (c < prev);
             const bool take_c = has & (c < cur);
             const uint64_t nw = take_prev ? prev : (take_c ? c : cur);
+            if (NREG > 1) {
+              // second register: its lane 0 follows lane 15 of the first (row_ror:1 brings it round)
+              const uint64_t cur1 = ((uint64_t)best_d1 << 32) | best_i1;
+              // (combined with a lane mask, not with a select: hipcc 7.2 miscompiles a select between two
+              // DPP moves -- lane 0 of the row reads 0; checked with a 20-line kernel on gfx950)
+              const uint32_t lane0 = tl == 0 ? 0xffffffffu : 0u;
+              const uint32_t qd = t_team_shr1(best_d1) | (t_dpp<0x121>(best_d) & lane0);
+              const uint32_t qi = t_team_shr1(best_i1) | (t_dpp<0x121>(best_i) & lane0);
+              const uint64_t prev1 = ((uint64_t)qd << 32) | qi;
+              const bool take_prev1 = has & (c < prev1);
+              const bool take_c1 = has & (c < cur1);
+              const uint64_t nw1 = take_prev1 ? prev1 : (take_c1 ? c : cur1);
+              best_d1 = (uint32_t)(nw1 >> 32);
+              best_i1 = (uint32_t)nw1;
+            }
             best_d = (uint32_t)(nw >> 32);
             best_i = (uint32_t)nw;
             pm &= ~__ballot(lane == src);  // the four lanes just served (a team without one names a lane that was not pending)
           } while (pm);
-          // gate from the k-th best of my team
-          const float w = __uint_as_float(t_lane_read(best_d, (team << 4) + a.k - 1));
-          tau2 = knn_gate_from_worst(w);
+          tau2 = knn_gate_from_worst(kth_dist());
         }
       }
     };
@@ -368,8 +388,7 @@ __device__ __forceinline__ void team_pass(const TeamArgs &a, const TeamLds &L, i
       exchange(t_xor4(best_d), t_xor4(best_i), up4);
       exchange(t_dpp<0x4e>(best_d), t_dpp<0x4e>(best_i), up2);
       exchange(t_dpp<0xb1>(best_d), t_dpp<0xb1>(best_i), up1);
-      const float w = __uint_as_float(t_lane_read(best_d, (team << 4) + a.k - 1));
-      tau2 = knn_gate_from_worst(w);
+      tau2 = knn_gate_from_worst(kth_dist());  // k > 16: the second register is still empty, the gate stays open
       first_sorted = true;
     }
     for (int base = 0; base < steps; base += 16) {
@@ -407,27 +426,32 @@ __device__ __forceinline__ void team_pass(const TeamArgs &a, const TeamLds &L, i
     if (SELECT) {
       // finished at this level (deviceCode.cu:118: k insertions happened): lane j < k stores neighbour j.
       // The query's own lane adds the intersection count and the level afterwards (team_kernel).
-      if (on && others >= (uint32_t)a.k && tl < a.k) {
+      if (on && others >= (uint32_t)a.k) {
         const int32_t out_row = __float_as_int(rec[6]);
-        const int64_t o = (int64_t)out_row * a.k + tl;
-        const uint64_t key = ((uint64_t)best_d << 32) | best_i;
-        const int32_t prim = knn_key_prim(key);
-        const float d = __uint_as_float(best_d);
-        if (a.out_idx) a.out_idx[o] = prim;
-        if (a.out_dist) a.out_dist[o] = d;
-        if (a.out_fb) {
-          // slot 0 of the row: everything but `intersections`, which only the query's lane writes
-          int2 *rec8 = (int2 *)(a.out_fb + o);
-          rec8[0] = make_int2(prim, __float_as_int(d));
-          rec8[1] = make_int2(tl == 0 ? 0 : a.k, 0);
-          if (tl != 0) rec8[2] = make_int2(0, 0);
+#pragma unroll
+        for (int reg = 0; reg < NREG; reg++) {
+          const int j = tl + 16 * reg;  // my entry of this register
+          if (j >= a.k) continue;
+          const uint32_t bd = reg == 0 ? best_d : best_d1, bi = reg == 0 ? best_i : best_i1;
+          const int64_t o = (int64_t)out_row * a.k + j;
+          const int32_t prim = knn_key_prim(((uint64_t)bd << 32) | bi);
+          const float d = __uint_as_float(bd);
+          if (a.out_idx) a.out_idx[o] = prim;
+          if (a.out_dist) a.out_dist[o] = d;
+          if (a.out_fb) {
+            // slot 0 of the row: everything but `intersections`, which only the query's lane writes
+            int2 *rec8 = (int2 *)(a.out_fb + o);
+            rec8[0] = make_int2(prim, __float_as_int(d));
+            rec8[1] = make_int2(j == 0 ? 0 : a.k, 0);
+            if (j != 0) rec8[2] = make_int2(0, 0);
+          }
         }
       }
     }
   }
 }
 
-template <bool HALO>
+template <bool HALO, int NREG>
 __global__ void __launch_bounds__(kTeamBlock) __attribute__((amdgpu_waves_per_eu(4))) team_kernel(TeamArgs a) {
   extern __shared__ __align__(16) unsigned char smem[];
   const int lane = threadIdx.x & 63;
@@ -726,7 +750,7 @@ __global__ void __launch_bounds__(kTeamBlock) __attribute__((amdgpu_waves_per_eu
       };
       {
         const int n_count = build_qlist(count_first);
-        if (!(TKNN_DIAG_BUILD && (a.diag & 4))) team_pass<false, HALO>(a, L, n_count, r_in0, m, own_pts, halo_pts, lane);
+        if (!(TKNN_DIAG_BUILD && (a.diag & 4))) team_pass<false, HALO, NREG>(a, L, n_count, r_in0, m, own_pts, halo_pts, lane);
         t_wave_sync();
       }
       PHASE_END(2);
@@ -748,7 +772,7 @@ __global__ void __launch_bounds__(kTeamBlock) __attribute__((amdgpu_waves_per_eu
       {
         t_wave_sync();
         const int n_select = build_qlist(select_now);
-        if (!(TKNN_DIAG_BUILD && (a.diag & 2))) team_pass<true, HALO>(a, L, n_select, r_in0, 1, own_pts, halo_pts, lane);
+        if (!(TKNN_DIAG_BUILD && (a.diag & 2))) team_pass<true, HALO, NREG>(a, L, n_select, r_in0, 1, own_pts, halo_pts, lane);
         t_wave_sync();
       }
       PHASE_END(3);
@@ -831,7 +855,7 @@ __global__ void __launch_bounds__(kTeamBlock) __attribute__((amdgpu_waves_per_eu
 
 }  // namespace
 
-bool Engine::team_kernel_supports(int k) { return k >= 1 && k <= 16; }
+bool Engine::team_kernel_supports(int k) { return k >= 1 && k <= 32; }
 
 // How many radius levels the first gather of every packet should serve: with the average density
 // of the scene, the first level at which a box is expected to hold about k/2 other points.  Only
@@ -880,7 +904,10 @@ bool Engine::solve_team(const SolveArgs &sa, tknnSolveInfo *info, hipStream_t s)
   int per_cu = 2;
   const size_t lds = (size_t)kTeamBlock / 64 * kTeamLds;
   const bool with_halo = halo_n_ > 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, with_halo ? team_kernel<true> : team_kernel<false>, kTeamBlock, lds) != hipSuccess) per_cu = 2;
+  const bool wide_list = sa.k > 16;  // two list registers per lane
+  const void *entry = with_halo ? (wide_list ? (const void *)team_kernel<true, 2> : (const void *)team_kernel<true, 1>)
+                                : (wide_list ? (const void *)team_kernel<false, 2> : (const void *)team_kernel<false, 1>);
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, entry, kTeamBlock, lds) != hipSuccess) per_cu = 2;
   per_cu = std::max(1, per_cu);
   const int64_t want = (a.ngroups + kTeamBlock / 64 - 1) / (kTeamBlock / 64);
   const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>(want, (int64_t)prop.multiProcessorCount * per_cu));
@@ -890,10 +917,14 @@ bool Engine::solve_team(const SolveArgs &sa, tknnSolveInfo *info, hipStream_t s)
   OWLMI_HIP(hipMemsetAsync(done_, 1, (size_t)n, s));
   if (sa.d_levels) OWLMI_HIP(hipMemsetAsync(sa.d_levels, 0xff, (size_t)n * sizeof(int32_t), s));
   OWLMI_HIP(hipEventRecord(ev_a_, s));
-  if (with_halo)
-    hipLaunchKernelGGL(team_kernel<true>, dim3(blocks), dim3(kTeamBlock), lds, s, a);
+  if (with_halo && wide_list)
+    hipLaunchKernelGGL((team_kernel<true, 2>), dim3(blocks), dim3(kTeamBlock), lds, s, a);
+  else if (with_halo)
+    hipLaunchKernelGGL((team_kernel<true, 1>), dim3(blocks), dim3(kTeamBlock), lds, s, a);
+  else if (wide_list)
+    hipLaunchKernelGGL((team_kernel<false, 2>), dim3(blocks), dim3(kTeamBlock), lds, s, a);
   else
-    hipLaunchKernelGGL(team_kernel<false>, dim3(blocks), dim3(kTeamBlock), lds, s, a);
+    hipLaunchKernelGGL((team_kernel<false, 1>), dim3(blocks), dim3(kTeamBlock), lds, s, a);
   OWLMI_HIP(hipGetLastError());
   OWLMI_HIP(hipEventRecord(ev_b_, s));
   OWLMI_HIP(hipMemcpyAsync(h_counters_, counters_, 10 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));

@@ -27,7 +27,7 @@ def test_golden_vectors(golden, kernel):
     eng = _engine()
     eng.build(golden["xyz"])
     k = int(golden["k"])
-    if kernel == _lib.KERNEL_TEAM and k > 16:
+    if kernel == _lib.KERNEL_TEAM and k > 32:
         with pytest.raises(_lib.TknnError):
             eng.solve(k, float(golden["start_radius"]), kernel=kernel)
         return
@@ -49,7 +49,8 @@ def test_golden_vectors(golden, kernel):
 
 
 @pytest.mark.parametrize("kernel", KERNELS, ids=KERNEL_IDS)
-@pytest.mark.parametrize("n,k,seed", [(100_000, 5, 0), (50_000, 10, 1), (30_000, 16, 2), (20_000, 3, 3)])
+@pytest.mark.parametrize("n,k,seed", [(100_000, 5, 0), (50_000, 10, 1), (30_000, 16, 2), (20_000, 3, 3),
+                                      (30_000, 17, 4), (40_000, 24, 5), (25_000, 32, 6)])
 def test_against_oracle_uniform(kernel, n, k, seed):
     xyz = datasets.uniform3d(n, seed=seed)
     r0 = datasets.start_radius(n, k)
