@@ -285,6 +285,7 @@ Engine::~Engine() {
   if (next_level_) (void)hipFree(next_level_);
   if (counters_) (void)hipFree(counters_);
   if (halo_mask_) (void)hipFree(halo_mask_);
+  if (slot_list_) (void)hipFree(slot_list_);
   if (h_counters_) (void)hipHostFree(h_counters_);
   if (wave_ws_) (void)hipFree(wave_ws_);
   if (ev_a_) (void)hipEventDestroy(ev_a_);

@@ -85,6 +85,8 @@ class Engine {
   void *wave_ws_ = nullptr;
   size_t wave_ws_bytes_ = 0;
   int wave_leaf_max_ = 16;  // subtrees of at most this many points are streamed as one range (TKNN_LEAF_MAX)
+  int32_t *slot_list_ = nullptr;  // compact list of the sorted slots the team kernel handed over (+ its length)
+  int64_t slot_list_cap_ = 0;
   unsigned long long *halo_mask_ = nullptr;  // per leaf block: peers it may have points for (+ 64 cursors)
   int64_t halo_mask_cap_ = 0;
   hipEvent_t ev_a_ = nullptr, ev_b_ = nullptr;

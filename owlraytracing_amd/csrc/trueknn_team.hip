@@ -28,6 +28,8 @@
 #include "knn_thresholds.h"  // knn_gate_from_worst
 #include "trueknn_engine.h"
 
+#include <hipcub/hipcub.hpp>
+
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
@@ -853,6 +855,253 @@ __global__ void __launch_bounds__(kTeamBlock) __attribute__((amdgpu_waves_per_eu
   }
 }
 
+
+// ---- team walk: the stragglers, one query per team, no packet lists --------------------------------
+// Queries the packet kernel hands over (outliers whose boxes have grown over whole clusters, dense
+// duplicates) have candidate sets far beyond its LDS lists.  Here a team walks the pyramid for ONE
+// query: its 16 lanes test 16 child boxes of a wide node at a time and push the survivors on the
+// team's LDS stack; a leaf block is 16 points = 16 lanes, tested, counted and selected exactly like
+// in the passes above.  A child box that lies inside the part of the query's box where the
+// candidate test is certain, and beyond the list's gate, is COUNTED (its points are consecutive
+// sorted slots: the count is arithmetic) instead of walked -- a box over a cluster of 100 000 points
+// costs a few hundred steps.  Levels loop inside the kernel (hostCode.cpp:285-340 per query).
+constexpr int kWalkStack = 384;  // stack entries per team: up to 63 siblings wait on each of <= 6 levels
+
+struct NotDone {
+  __host__ __device__ bool operator()(uint8_t d) const { return d == 0; }
+};
+
+struct WalkLevel {  // per tree and pyramid level, in LDS: lanes of different teams are at different levels
+  const LbvhBox *boxes;
+  int32_t count;
+  int32_t pad_;
+};
+
+template <bool HALO, int NREG>
+__global__ void __launch_bounds__(kTeamBlock) team_walk_kernel(TeamArgs a, const int32_t *slots, int32_t nslots) {
+  __shared__ int32_t stack_mem[4 * kWalkStack];
+  __shared__ WalkLevel levels[2][LBVH_WIDE_LEVELS];
+  const int lane = threadIdx.x & 63, team = lane >> 4, tl = lane & 15;
+  int32_t *stack = stack_mem + team * kWalkStack;
+  if (lane < 2 * LBVH_WIDE_LEVELS) {
+    const int t = lane / LBVH_WIDE_LEVELS, l = lane % LBVH_WIDE_LEVELS;
+    levels[t][l].boxes = a.wide[t].level[l];
+    levels[t][l].count = a.wide[t].count[l];
+  }
+  t_wave_sync();
+  unsigned long long isect_sum = 0, levels_sum = 0, node_tests = 0, point_tests = 0;
+  unsigned int unfinished = 0, failed = 0;
+  int max_level = 0;
+  for (;;) {
+    int base = 0;
+    if (lane == 0) base = (int)atomicAdd(&a.counters[0], 4ull);
+    base = __builtin_amdgcn_readfirstlane(base);
+    if (base >= nslots) break;
+    const bool has_q = base + team < nslots;
+    const int32_t slot = has_q ? slots[base + team] : 0;
+    const LbvhPoint q = a.bvh.points[slot];
+    const int32_t row = a.bvh.prim_id[slot];
+    int level = has_q ? a.next_level[slot] : 0;
+    int64_t isect = has_q ? a.isect_sorted[slot] : 0;
+    float r = a.start_radius;
+    for (int i = 0; i < level; i++) r = r * 2.0f;
+    bool active = has_q;
+    while (__ballot(active) != 0ull) {  // one radius level for every team that is still at work
+      const float mg = (fmaxf(fmaxf(fabsf(q.x), fabsf(q.y)), fabsf(q.z)) + 2.0f * r) * 4.76837158203125e-07f;  // 2^-21
+      const float in_below = r - mg, in_upto = r + mg;
+      // boxes that can hold a candidate meet [q - r - 2M, q + r + 2M]; every point of a box inside
+      // [q - r + 2M, q + r - 2M] certainly is one
+      const float rl = r + 2.0f * mg, rs = r - 2.0f * mg;
+      uint32_t part = 0;  // my lane's share of the candidate count of this level
+      uint32_t best_d = 0x7f7fffffu, best_i = 0u, best_d1 = 0x7f7fffffu, best_i1 = 0u;
+      float tau2 = INFINITY;
+      bool overflow = false;
+      auto kth_dist = [&]() -> float {
+        const uint32_t reg = (NREG > 1 && a.k > 16) ? best_d1 : best_d;
+        return __uint_as_float(t_lane_read(reg, (team << 4) + ((a.k - 1) & 15)));
+      };
+      for (int tree = 0; tree < (HALO ? 2 : 1); tree++) {
+        const LbvhWideView &wv = a.wide[tree];
+        const LbvhView &tv = tree == 0 ? a.bvh : a.halo;
+        if (tv.n <= 0 || wv.levels <= 0) continue;
+        const int32_t clean_end = tv.n - (tv.nan_count ? *tv.nan_count : 0);  // NaN points sort last
+        int sp = 0;
+        if (active) {
+          if (tl == 0) stack[0] = (wv.levels << 26) | 0;  // virtual root above the top level
+          sp = 1;
+        }
+        t_wave_sync();
+        while (__ballot(sp > 0) != 0ull) {
+          const bool work = sp > 0;
+          const int32_t e = work ? stack[sp - 1] : (1 << 26);
+          if (work) sp--;
+          const int lvl = (e >> 26) - 1;  // level of the children
+          const int32_t first_child = (e & 0x3ffffff) * 64;
+          const WalkLevel wl = levels[tree][lvl];
+          // the virtual root has the top level's few boxes as its children
+          const int32_t nchild = lvl == wv.levels - 1 ? (first_child == 0 ? wl.count : 0) : wl.count;
+          for (int chunk = 0; chunk < 4; chunk++) {
+            const int32_t c = first_child + 16 * chunk + tl;
+            const bool valid = work && c < nchild;
+            LbvhBox bx = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
+            if (valid) bx = wl.boxes[c];
+            const bool ov = valid & (bx.lo[0] <= q.x + rl) & (bx.hi[0] >= q.x - rl) & (bx.lo[1] <= q.y + rl) &
+                            (bx.hi[1] >= q.y - rl) & (bx.lo[2] <= q.z + rl) & (bx.hi[2] >= q.z - rl);
+            node_tests += valid ? 1u : 0u;
+            // inside the certain part of my box and beyond the gate: count, do not walk
+            bool counted = false;
+            if (ov) {
+              const bool inside = (bx.lo[0] >= q.x - rs) & (bx.hi[0] <= q.x + rs) & (bx.lo[1] >= q.y - rs) &
+                                  (bx.hi[1] <= q.y + rs) & (bx.lo[2] >= q.z - rs) & (bx.hi[2] <= q.z + rs);
+              if (inside) {
+                const float gx = fmaxf(fmaxf(bx.lo[0] - q.x, q.x - bx.hi[0]), 0.f), gy = fmaxf(fmaxf(bx.lo[1] - q.y, q.y - bx.hi[1]), 0.f),
+                            gz = fmaxf(fmaxf(bx.lo[2] - q.z, q.z - bx.hi[2]), 0.f);
+                const float m2 = (gx * gx + gy * gy) + gz * gz;
+                const int64_t span = (int64_t)LBVH_BLOCK << (6 * lvl);  // points under one child of this level
+                const int64_t first = (int64_t)c * span;
+                if (m2 * 0.999995f > tau2 && first + span <= (int64_t)clean_end) {
+                  part += (uint32_t)span;
+                  counted = true;
+                }
+              }
+            }
+            const bool keep = ov && !counted;
+            const uint32_t keep_mine = (uint32_t)(__ballot(keep) >> (team * 16)) & 0xffffu;
+            if (lvl > 0) {
+              if (sp + __popc(keep_mine) > kWalkStack) {
+                overflow = true;
+              } else {
+                if (keep) stack[sp + __popc(keep_mine & ((1u << tl) - 1u))] = (lvl << 26) | c;
+                sp += __popc(keep_mine);
+              }
+            } else {
+              // children are leaf blocks: lanes become the 16 points of one block at a time
+              uint32_t todo = keep_mine;
+              while (__ballot(todo != 0u) != 0ull) {
+                const bool has_b = todo != 0u;
+                const int32_t b = first_child + 16 * chunk + (has_b ? __ffs((int)todo) - 1 : 0);
+                todo &= todo - 1u;
+                LbvhPoint p = {__uint_as_float(0x7fc00000u), 0.f, 0.f, -1};
+                if (has_b) p = tv.points[(int64_t)b * LBVH_BLOCK + tl];
+                point_tests += has_b ? 1u : 0u;
+                const float dx = p.x - q.x, dy = p.y - q.y, dz = p.z - q.z;
+                const float t = has_b ? fmaxf(fmaxf(fabsf(dx), fabsf(dy)), fabsf(dz)) : __uint_as_float(0x7fc00000u);
+                unsigned long long in_m = __ballot(t <= in_below);
+                const unsigned long long maybe_m = __ballot(t <= in_upto) & ~in_m;
+                if (maybe_m) in_m |= maybe_m & __ballot(knn_in_box(p.x, p.y, p.z, r, q.x, q.y, q.z));
+                part = t_count(part, in_m);
+                const float d2 = t_dist2(dx, dy, dz);
+                unsigned long long pm = in_m & __ballot(p.id != q.id) & __ballot(d2 <= tau2);
+                if (pm) {
+                  const uint32_t key_d = __float_as_uint(knn_sqrt(d2));
+                  const uint32_t key_i = (uint32_t)p.id;
+                  do {
+                    const uint32_t pending_mine = (uint32_t)(pm >> (team * 16)) & 0xffffu;
+                    const bool has = pending_mine != 0u;
+                    const int src = (team << 4) + (has ? __ffs((int)pending_mine) - 1 : 0);
+                    const uint32_t cd = t_lane_read(key_d, src), ci = t_lane_read(key_i, src);
+                    const uint64_t cc = ((uint64_t)cd << 32) | ci;
+                    const uint64_t cur = ((uint64_t)best_d << 32) | best_i;
+                    const uint32_t pd = t_team_shr1(best_d), pi = t_team_shr1(best_i);
+                    const uint64_t prev = ((uint64_t)pd << 32) | pi;
+                    const bool take_prev = has & (tl != 0) & (cc < prev);
+                    const bool take_c = has & (cc < cur);
+                    const uint64_t nw = take_prev ? prev : (take_c ? cc : cur);
+                    if (NREG > 1) {
+                      const uint64_t cur1 = ((uint64_t)best_d1 << 32) | best_i1;
+                      const uint32_t lane0 = tl == 0 ? 0xffffffffu : 0u;
+                      const uint32_t qd = t_team_shr1(best_d1) | (t_dpp<0x121>(best_d) & lane0);
+                      const uint32_t qi = t_team_shr1(best_i1) | (t_dpp<0x121>(best_i) & lane0);
+                      const uint64_t prev1 = ((uint64_t)qd << 32) | qi;
+                      const bool take_prev1 = has & (cc < prev1);
+                      const bool take_c1 = has & (cc < cur1);
+                      const uint64_t nw1 = take_prev1 ? prev1 : (take_c1 ? cc : cur1);
+                      best_d1 = (uint32_t)(nw1 >> 32);
+                      best_i1 = (uint32_t)nw1;
+                    }
+                    best_d = (uint32_t)(nw >> 32);
+                    best_i = (uint32_t)nw;
+                    pm &= ~__ballot(lane == src);
+                  } while (pm);
+                  tau2 = knn_gate_from_worst(kth_dist());
+                }
+              }
+            }
+          }
+          t_wave_sync();
+        }
+      }
+      // ---- the level's outcome, per team ----
+      const uint32_t cnt = t_team_sum(part);
+      const uint32_t others = cnt ? cnt - 1u : 0u;  // a query lies in its own box
+      const bool fin = active && !overflow && others >= (uint32_t)a.k;
+      if (active && overflow) {  // stack exhausted: leave the query to the lane rounds, state untouched
+        failed += tl == 0 ? 1u : 0u;
+        active = false;
+      } else if (active) {
+        isect += cnt;
+        levels_sum += tl == 0 ? 1ull : 0ull;
+        if (fin) {
+#pragma unroll
+          for (int reg = 0; reg < NREG; reg++) {
+            const int j = tl + 16 * reg;
+            if (j >= a.k) continue;
+            const uint32_t bd = reg == 0 ? best_d : best_d1, bi = reg == 0 ? best_i : best_i1;
+            const int64_t o = (int64_t)row * a.k + j;
+            const int32_t prim = knn_key_prim(((uint64_t)bd << 32) | bi);
+            const float d = __uint_as_float(bd);
+            if (a.out_idx) a.out_idx[o] = prim;
+            if (a.out_dist) a.out_dist[o] = d;
+            if (a.out_fb) {
+              tknnNeigh ev;
+              ev.ind = prim;
+              ev.dist = d;
+              ev.numNeighbors = j == 0 ? 0 : a.k;
+              ev.pad_ = 0;
+              ev.intersections = j == 0 ? isect : 0;
+              a.out_fb[o] = ev;
+            }
+          }
+          if (tl == 0) {
+            if (a.out_isect) a.out_isect[row] = isect;
+            if (a.out_level) a.out_level[row] = level;
+            a.done[slot] = 1;
+            isect_sum += (unsigned long long)isect;
+          }
+          max_level = max(max_level, level + 1);
+          active = false;
+        } else {
+          level++;
+          r = r * 2.0f;  // hostCode.cpp:321
+          if (level >= a.max_rounds) {
+            // out of rounds: the caller decides (allow_unfinished); the state says where it stopped
+            if (tl == 0) {
+              a.isect_sorted[slot] = isect;
+              a.next_level[slot] = level;
+              unfinished++;
+            }
+            max_level = max(max_level, level);
+            active = false;
+          }
+        }
+      }
+    }
+  }
+  const unsigned long long isum = t_wave_sum(isect_sum), lsum = t_wave_sum(levels_sum), nt = t_wave_sum(node_tests),
+                           pt = t_wave_sum(point_tests) * LBVH_BLOCK / 16, usum = t_wave_sum((unsigned long long)unfinished),
+                           fsum = t_wave_sum((unsigned long long)failed);
+  const int ml = (int)t_wave_max((float)max_level);
+  if (lane == 0) {
+    atomicMax(&a.counters[1], (unsigned long long)ml);
+    atomicAdd(&a.counters[2], nt);
+    atomicAdd(&a.counters[3], pt);
+    atomicAdd(&a.counters[4], isum);
+    atomicAdd(&a.counters[6], lsum);
+    if (usum) atomicAdd(&a.counters[7], usum);
+    if (fsum) atomicAdd(&a.counters[8], fsum);
+  }
+}
+
 }  // namespace
 
 bool Engine::team_kernel_supports(int k) { return k >= 1 && k <= 32; }
@@ -971,22 +1220,87 @@ bool Engine::solve_team(const SolveArgs &sa, tknnSolveInfo *info, hipStream_t s)
   }
   const unsigned long long handed = h_counters_[8];
   if (handed) {
-    // Stragglers whose candidate lists outgrew the LDS lists.  A few (outliers of a clustered set,
-    // whose boxes grow over whole clusters): per-round lane launches from the level at which each
-    // was handed over, with subtree counting.  Many (a start radius far too large for the density:
-    // hundreds of candidates per query from level 0 on): the wave-packet kernel, which streams
-    // candidate sets of any size, re-solves just those queries.
+    // Stragglers whose candidate lists outgrew the LDS lists (outliers of a clustered set, whose boxes
+    // grow over whole clusters; dense duplicates): team_walk_kernel, one query per team, from the level
+    // at which each was handed over; what exhausts its stack goes on to per-round lane launches.  A
+    // quarter or more of all queries (a start radius far too large for the density: hundreds of
+    // candidates per query from level 0 on): the wave-packet kernel, which streams candidate sets of
+    // any size, re-solves just those queries.
     tknnSolveInfo tail;
     std::memset(&tail, 0, sizeof tail);
-    const char *force = getenv("TKNN_TEAM_TAIL");  // "lane" / "wave": measurements only
+    const char *force = getenv("TKNN_TEAM_TAIL");  // "walk" / "lane" / "wave": tests and measurements only
     const bool by_wave = wave_kernel_available() && (force ? !strcmp(force, "wave") : handed * 4ull >= (unsigned long long)n);
-    if (by_wave)
+    const bool by_walk = !by_wave && !(force && !strcmp(force, "lane"));
+    const int first_handover_level = (int)h_counters_[9];
+    if (by_wave) {
       solve_wave(sa, &tail, s, /*only_unfinished=*/true);
-    else
-      continue_lane(sa, (int)h_counters_[9], &tail, s);
+    } else if (by_walk) {
+      // one query per team (team_walk_kernel): the stragglers' sorted slots as a compact ascending list
+      if (n > slot_list_cap_) {
+        if (slot_list_) (void)hipFree(slot_list_);
+        slot_list_ = nullptr;
+        OWLMI_HIP(hipMalloc((void **)&slot_list_, ((size_t)n + 1) * sizeof(int32_t)));
+        slot_list_cap_ = n;
+      }
+      int32_t *d_count = slot_list_ + n;
+      hipcub::CountingInputIterator<int32_t> iota(0);
+      hipcub::TransformInputIterator<bool, NotDone, const uint8_t *> flags(done_, NotDone{});
+      size_t tmp_bytes = 0;
+      OWLMI_HIP(hipcub::DeviceSelect::Flagged(nullptr, tmp_bytes, iota, flags, slot_list_, d_count, (int)n, s));
+      if (tmp_bytes > wave_ws_bytes_) {
+        if (wave_ws_) (void)hipFree(wave_ws_);
+        wave_ws_ = nullptr;
+        OWLMI_HIP(hipMalloc(&wave_ws_, tmp_bytes));
+        wave_ws_bytes_ = tmp_bytes;
+      }
+      OWLMI_HIP(hipcub::DeviceSelect::Flagged(wave_ws_, tmp_bytes, iota, flags, slot_list_, d_count, (int)n, s));
+      OWLMI_HIP(hipMemsetAsync(counters_, 0, 16 * sizeof(unsigned long long), s));
+      const int walk_blocks = (int)std::min<int64_t>((int64_t)(handed + 3) / 4, (int64_t)prop.multiProcessorCount * 16);
+      OWLMI_HIP(hipEventRecord(ev_a_, s));
+      if (with_halo && wide_list)
+        hipLaunchKernelGGL((team_walk_kernel<true, 2>), dim3(walk_blocks), dim3(kTeamBlock), 0, s, a, slot_list_, (int32_t)handed);
+      else if (with_halo)
+        hipLaunchKernelGGL((team_walk_kernel<true, 1>), dim3(walk_blocks), dim3(kTeamBlock), 0, s, a, slot_list_, (int32_t)handed);
+      else if (wide_list)
+        hipLaunchKernelGGL((team_walk_kernel<false, 2>), dim3(walk_blocks), dim3(kTeamBlock), 0, s, a, slot_list_, (int32_t)handed);
+      else
+        hipLaunchKernelGGL((team_walk_kernel<false, 1>), dim3(walk_blocks), dim3(kTeamBlock), 0, s, a, slot_list_, (int32_t)handed);
+      OWLMI_HIP(hipGetLastError());
+      OWLMI_HIP(hipEventRecord(ev_b_, s));
+      OWLMI_HIP(hipMemcpyAsync(h_counters_, counters_, 10 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+      OWLMI_HIP(hipStreamSynchronize(s));
+      float walk_ms = 0;
+      OWLMI_HIP(hipEventElapsedTime(&walk_ms, ev_a_, ev_b_));
+      tail.rounds = (int)h_counters_[1];
+      tail.node_tests = (int64_t)h_counters_[2];
+      tail.point_tests = (int64_t)h_counters_[3];
+      tail.total_intersections = (int64_t)h_counters_[4];
+      tail.total_active_rounds = (int64_t)h_counters_[6];
+      tail.unfinished = (int64_t)h_counters_[7];
+      tail.solve_ms = walk_ms;
+      tail.dominant_kernel_launches = 1;
+      const unsigned long long left = h_counters_[8];  // stack exhausted: state untouched, lane rounds take them
+      if (tail.unfinished && !sa.allow_unfinished) throw RoundsExceeded{};
+      if (left) {
+        tknnSolveInfo rest;
+        std::memset(&rest, 0, sizeof rest);
+        continue_lane(sa, first_handover_level, &rest, s);
+        tail.rounds = std::max(tail.rounds, rest.rounds);
+        tail.node_tests += rest.node_tests;
+        tail.point_tests += rest.point_tests;
+        tail.total_intersections += rest.total_intersections;
+        tail.total_active_rounds += rest.total_active_rounds;
+        tail.unfinished += rest.unfinished;
+        tail.solve_ms += rest.solve_ms;
+        tail.dominant_kernel_launches += rest.dominant_kernel_launches;
+      }
+    } else {
+      continue_lane(sa, first_handover_level, &tail, s);
+    }
     if (getenv("TKNN_VERBOSE"))
-      fprintf(stderr, "[team] %llu of %lld queries handed over from level %llu on: team kernel %.2f ms, %s %.2f ms (%d launches)\n",
-              handed, (long long)n, h_counters_[9], ms, by_wave ? "wave kernel" : "lane rounds", tail.solve_ms, tail.dominant_kernel_launches);
+      fprintf(stderr, "[team] %llu of %lld queries handed over from level %d on: team kernel %.2f ms, %s %.2f ms (%d launches)\n",
+              handed, (long long)n, first_handover_level, ms, by_wave ? "wave kernel" : (by_walk ? "team walk" : "lane rounds"), tail.solve_ms,
+              tail.dominant_kernel_launches);
     if (info) {
       info->rounds = std::max(info->rounds, tail.rounds);
       float radius = sa.start_radius;

@@ -136,6 +136,27 @@ def test_points_with_nan_coordinates_are_nobodys_candidates(kernel):
     eng.close()
 
 
+@pytest.mark.parametrize("tail", ["walk", "lane", "wave"])
+@pytest.mark.parametrize("k", [7, 24])
+def test_team_kernel_tails_agree_when_everything_is_handed_over(monkeypatch, tail, k):
+    """A start radius far too large for the density of the cluster cores: nearly every packet outgrows the team kernel's LDS lists
+    at level 0, so the rows come from its tail -- the team walk (one query per team, subtrees counted),
+    the lane rounds or the wave kernel in subset mode.  Each must reproduce the checker."""
+    monkeypatch.setenv("TKNN_TEAM_TAIL", tail)
+    xyz = datasets.gaussian_mixture3d(40_000, components=3, sigma=0.004, seed=13)
+    xyz[::7] = xyz[1::7][: len(xyz[::7])]  # duplicates
+    ref = oracle.trueknn(xyz, k, 0.002)
+    eng = _engine()
+    eng.build(xyz)
+    r = eng.solve(k, 0.002, kernel=_lib.KERNEL_TEAM)
+    assert r["info"]["rounds"] == ref["rounds"] and ref["rounds"] >= 3  # the sparse fringe needs more levels
+    assert np.array_equal(r["intersections"].cpu().numpy(), ref["intersections"])
+    assert np.array_equal(r["idx"].cpu().numpy(), ref["idx"])
+    assert np.array_equal(r["dist"].cpu().numpy().view(np.int32), ref["dist"].view(np.int32))
+    assert r["info"]["total_intersections"] == int(ref["intersections"].sum())
+    eng.close()
+
+
 def test_candidate_thresholds_equal_the_literal_box_test():
     """lo <= c <= hi must select exactly the c with fl(c - r) <= q <= fl(c + r), including near
     zero, across binades and at exact box boundaries (where a per-ulp walk would take forever)."""
