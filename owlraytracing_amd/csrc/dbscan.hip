@@ -90,44 +90,70 @@ __device__ __forceinline__ void uf_unite(int32_t *parent, int32_t a, int32_t b) 
 // f(representative's row) for every tight node that has a core point within eps of q (its first core
 // point stands for all of them) and for every core point within eps reached as a leaf.  `own_slot`
 // (or -1) names q's own sorted slot: the tight node holding it is skipped.
-template <typename F>
-__device__ __forceinline__ void for_each_core_group(const DbArgs &a, const LbvhPoint &q, int32_t own_slot, F f) {
+// `settled(row)` may say that the group a tight node's first core point stands for needs no look
+// (the union kernel: already in my set), sparing the distance tests and the probe.
+template <typename S, typename F>
+__device__ __forceinline__ void for_each_core_group(const DbArgs &a, const LbvhPoint &q, int32_t own_slot, S settled, F f) {
   const LbvhView &bvh = a.bvh;
   const float r = a.eps_wide;
   int32_t ref = bvh.root;
+  // A tight node the sphere cuts through is PROBED, not scanned: the walk goes on below it (its
+  // descendants are tight too: inside -> hit, outside -> skipped) and leaves the subtree through the
+  // node's own rope at the first core point found within eps -- one is enough, the node is one group.
+  int32_t probe_rep = -1, probe_exit = LBVH_END;
   while (ref != LBVH_END) {
+    if (probe_rep >= 0 && ref == probe_exit) probe_rep = -1;  // left the probed subtree without a hit
     if (ref >= 0) {
       const LbvhNode nd = bvh.nodes[ref];
       const bool hit = (nd.lo[0] - r <= q.x) & (q.x <= nd.hi[0] + r) & (nd.lo[1] - r <= q.y) & (q.y <= nd.hi[1] + r) &
                        (nd.lo[2] - r <= q.z) & (q.z <= nd.hi[2] + r);
-      if (hit && node_is_tight(nd, a.eps_in2)) {
-        const int32_t first = lbvh_first(ref, nd.other), last = lbvh_last(ref, nd.other);
-        int32_t s = a.next_core[first];
-        if (s <= last && !(first <= own_slot && own_slot <= last)) {
-          float far2, near2;
-          box_dist2(nd, q, far2, near2);
-          if (far2 <= a.eps_in2) {
-            f(bvh.prim_id[s]);
-          } else if (near2 <= a.eps_out2) {
-            const int32_t rep_id = bvh.prim_id[s];
-            for (; s <= last; s = a.next_core[s + 1]) {
-              const LbvhPoint p = bvh.points[s];
-              if (knn_sqrt(knn_dist2(p.x, p.y, p.z, q.x, q.y, q.z)) <= a.eps) {
-                f(rep_id);
-                break;
-              }
-            }
-          }
-        }
+      if (!hit) {
         ref = bvh.rope_node[ref];
         continue;
       }
-      ref = hit ? lbvh_left_ref(ref, nd) : bvh.rope_node[ref];
+      const bool probing = probe_rep >= 0;
+      if (probing || node_is_tight(nd, a.eps_in2)) {
+        const int32_t first = lbvh_first(ref, nd.other), last = lbvh_last(ref, nd.other);
+        const int32_t s = a.next_core[first];
+        if (s > last || (first <= own_slot && own_slot <= last)) {  // no core point here / my own group
+          ref = bvh.rope_node[ref];
+          continue;
+        }
+        if (!probing && settled(bvh.prim_id[s])) {
+          ref = bvh.rope_node[ref];
+          continue;
+        }
+        float far2, near2;
+        box_dist2(nd, q, far2, near2);
+        if (far2 <= a.eps_in2) {  // every point of the node is within eps
+          f(probing ? probe_rep : bvh.prim_id[s]);
+          ref = probing ? probe_exit : bvh.rope_node[ref];
+          probe_rep = -1;
+          continue;
+        }
+        if (near2 > a.eps_out2) {  // none is
+          ref = bvh.rope_node[ref];
+          continue;
+        }
+        if (!probing) {
+          probe_rep = bvh.prim_id[s];
+          probe_exit = bvh.rope_node[ref];
+        }
+      }
+      ref = lbvh_left_ref(ref, nd);
     } else {
       const int32_t slot = ~ref;
       if (a.core_sorted[slot] && slot != own_slot) {
         const LbvhPoint p = bvh.points[slot];
-        if (knn_sqrt(knn_dist2(p.x, p.y, p.z, q.x, q.y, q.z)) <= a.eps) f(bvh.prim_id[slot]);
+        if (knn_sqrt(knn_dist2(p.x, p.y, p.z, q.x, q.y, q.z)) <= a.eps) {
+          if (probe_rep >= 0) {
+            f(probe_rep);
+            ref = probe_exit;
+            probe_rep = -1;
+            continue;
+          }
+          f(bvh.prim_id[slot]);
+        }
       }
       ref = bvh.rope_leaf[slot];
     }
@@ -144,6 +170,23 @@ __global__ void __launch_bounds__(kDbBlock) db_core_kernel(DbArgs a) {
   const int32_t clean_end = bvh.n - (bvh.nan_count ? *bvh.nan_count : 0);  // NaN points sort last
   const float r = a.eps_wide;
   int32_t ref = bvh.root;
+  if (!a.want_counts) {
+    // the first tight node on my own root path: its points are pairwise within eps, so if it holds
+    // minPts of them I am core without looking any further
+    int32_t node = bvh.root;
+    while (node >= 0) {
+      const LbvhNode nd = bvh.nodes[node];
+      if (node_is_tight(nd, a.eps_in2)) {
+        const int32_t first = lbvh_first(node, nd.other), last = lbvh_last(node, nd.other);
+        if (last < clean_end && last - first + 1 >= a.min_pts) {
+          cnt = last - first + 1;
+          ref = LBVH_END;
+        }
+        break;
+      }
+      node = t <= nd.split ? lbvh_left_ref(node, nd) : lbvh_right_ref(node, nd);
+    }
+  }
   while (ref != LBVH_END && cnt < stop_at) {
     if (ref >= 0) {
       const LbvhNode nd = bvh.nodes[ref];
@@ -202,26 +245,66 @@ __global__ void __launch_bounds__(kDbBlock) db_next_core_kernel(DbArgs a, const 
 }
 
 __global__ void __launch_bounds__(kDbBlock) db_union_kernel(DbArgs a) {
+  // The 256 Morton-consecutive points of a workgroup mostly share a tight node and meet the same
+  // neighbouring tight nodes: every (my group, other group) pair would be united hundreds of times,
+  // each a pair of union-find walks through global atomics.  A direct-mapped LDS table of the pairs
+  // this workgroup has already taken care of drops the repeats (a stale or raced entry only costs a
+  // redundant unite; the pair that set an entry is united by the lane that set it).
+  constexpr int kPairs = 2048;
+  __shared__ unsigned long long seen[kPairs];
+  for (int i = threadIdx.x; i < kPairs; i += kDbBlock) seen[i] = ~0ull;
+  __syncthreads();
   const int32_t t = blockIdx.x * kDbBlock + threadIdx.x;
   if (t >= a.bvh.n || !a.core_sorted[t]) return;
   const LbvhView &bvh = a.bvh;
   const LbvhPoint q = bvh.points[t];
   const int32_t row = bvh.prim_id[t];
   // the first tight node on my own root path: its core points are one cluster, held together by its
-  // first core point
+  // first core point, which also stands for me in the unions below
+  int32_t mine = row;
   int32_t node = bvh.root;
   while (node >= 0) {
     const LbvhNode nd = bvh.nodes[node];
     if (node_is_tight(nd, a.eps_in2)) {
       const int32_t s = a.next_core[lbvh_first(node, nd.other)];  // <= t: I am core and inside
-      if (s != t) uf_unite(a.parent, row, bvh.prim_id[s]);
+      if (s != t) {
+        mine = bvh.prim_id[s];
+        uf_unite(a.parent, row, mine);
+      }
       break;
     }
     node = t <= nd.split ? lbvh_left_ref(node, nd) : lbvh_right_ref(node, nd);
   }
-  for_each_core_group(a, q, t, [&](int32_t other) {
-    if (other != row) uf_unite(a.parent, row, other);
-  });
+  auto slot_of = [&](int32_t other, unsigned long long &key) -> unsigned long long * {
+    const uint32_t lo = (uint32_t)min(mine, other), hi = (uint32_t)max(mine, other);
+    key = ((unsigned long long)hi << 32) | lo;
+    const uint32_t h = (lo * 0x9e3779b1u) ^ (hi * 0x85ebca6bu);
+    return seen + ((h >> 11) & (kPairs - 1));
+  };
+  int32_t my_root = uf_find(a.parent, mine);
+  for_each_core_group(
+      a, q, t,
+      [&](int32_t other) -> bool {  // is that group in my set already?  (then there is nothing to find out)
+        if (other == mine) return true;
+        unsigned long long key;
+        unsigned long long *slot = slot_of(other, key);
+        if (*(volatile unsigned long long *)slot == key) return true;
+        if (uf_find(a.parent, other) != my_root) {
+          my_root = uf_find(a.parent, my_root);  // my root may have been hooked under another meanwhile
+          if (uf_find(a.parent, other) != my_root) return false;
+        }
+        *(volatile unsigned long long *)slot = key;
+        return true;
+      },
+      [&](int32_t other) {
+        if (other == mine || other == row) return;
+        unsigned long long key;
+        unsigned long long *slot = slot_of(other, key);
+        if (*(volatile unsigned long long *)slot == key) return;
+        *(volatile unsigned long long *)slot = key;
+        uf_unite(a.parent, mine, other);
+        my_root = uf_find(a.parent, mine);
+      });
 }
 
 // after the unions: point every core at its root and flag roots for the ranking scan
@@ -247,10 +330,12 @@ __global__ void __launch_bounds__(kDbBlock) db_label_kernel(DbArgs a) {
   if (a.core_sorted[t]) {
     root = uf_find(a.parent, row);
   } else {
-    for_each_core_group(a, q, -1, [&](int32_t other) {
-      const int32_t r = uf_find(a.parent, other);
-      if (root < 0 || r < root) root = r;
-    });
+    for_each_core_group(
+        a, q, -1, [](int32_t) { return false; },
+        [&](int32_t other) {
+          const int32_t r = uf_find(a.parent, other);
+          if (root < 0 || r < root) root = r;
+        });
   }
   a.labels[row] = root < 0 ? -1 : a.rank[root];
 }
@@ -269,10 +354,12 @@ __global__ void __launch_bounds__(kDbBlock) db_assign_kernel(DbArgs a, const int
   int32_t best = core_label[row];
   if (best < 0) {
     best = -1;
-    for_each_core_group(a, q, -1, [&](int32_t other) {
-      const int32_t l = core_label[other];  // a tight node's core points share one label: its first stands for all
-      if (best < 0 || l < best) best = l;
-    });
+    for_each_core_group(
+        a, q, -1, [](int32_t) { return false; },
+        [&](int32_t other) {
+          const int32_t l = core_label[other];  // a tight node's core points share one label: its first stands for all
+          if (best < 0 || l < best) best = l;
+        });
   }
   a.labels[row] = best;
 }
