@@ -65,7 +65,7 @@ enum {
   TKNN_KERNEL_AUTO = 0,
   TKNN_KERNEL_LANE = 1,  /* one query per lane, stackless rope traversal, one launch per round    */
   TKNN_KERNEL_WAVE = 2,  /* one 64-query packet per wave, persistent, all rounds in one launch    */
-  TKNN_KERNEL_TEAM = 3   /* 16-lane teams, lanes = candidates of one query's leaf blocks; k <= 32  */
+  TKNN_KERNEL_TEAM = 3   /* 16-lane teams, lanes = candidates of one query's leaf blocks           */
 };
 
 typedef struct {

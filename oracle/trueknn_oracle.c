@@ -34,7 +34,12 @@
  *   (2) visit order of candidates is unspecified in the reference; the canonical order here is
  *       ascending primitive index, which together with the strict '<' of deviceCode.cu:116,125
  *       yields rows ordered by (dist, index).  Other orders are selectable to test that only
- *       ties depend on it.
+ *       ties depend on it.  One exception, because the lists persist over rounds
+ *       (deviceCode.cu:77-85 skips what is listed already): of two candidates at bit-identical fp32
+ *       distances the one that entered in an EARLIER round stays ahead whatever its index.  This
+ *       replay reproduces that; the HIP engines order all exact ties by index (a handful of rows
+ *       per million; tests/conftest.py::assert_rows_equal_modulo_cross_round_ties checks that
+ *       nothing else differs).
  *   (3) distance arithmetic: d = sqrtf((dx*dx + dy*dy) + dz*dz), every operation rounded to fp32
  *       on its own, i.e. deviceCode.cu:110-113 exactly as written, and a correctly rounded IEEE
  *       sqrt.  The reference's Release build lets nvcc contract the sum into fmas of its choosing

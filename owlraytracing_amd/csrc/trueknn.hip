@@ -480,9 +480,9 @@ int64_t Engine::repair_exact(int k, float start_radius, const int32_t *d_levels,
 
 void Engine::solve(const SolveArgs &sa, int kernel, tknnSolveInfo *info, hipStream_t s) {
   if (kernel == TKNN_KERNEL_TEAM && !team_kernel_supports(sa.k))
-    throw ArgError{TKNN_E_UNSUPPORTED, "the team kernel holds up to two neighbours per lane of a 16-lane team: k <= 32"};
+    throw ArgError{TKNN_E_UNSUPPORTED, "the team kernels hold up to four neighbours per lane of a 16-lane team: k <= 64"};
   if (kernel == TKNN_KERNEL_AUTO) {
-    // team kernel for k <= 32: it hands what it cannot hold (outliers, dense duplicates, start radii
+    // team kernels for every k the engine takes (<= 64; above 32 the team walk alone): they hand what it cannot hold (outliers, dense duplicates, start radii
     // far too large) to lane rounds or the wave kernel by itself; measured fastest from r0 = 2e-5 to
     // r0 = 0.04 on 10 M uniform points and on the clustered sets of profiles/
     if (team_kernel_supports(sa.k))

@@ -898,7 +898,7 @@ __global__ void __launch_bounds__(kTeamBlock) team_walk_kernel(TeamArgs a, const
     base = __builtin_amdgcn_readfirstlane(base);
     if (base >= nslots) break;
     const bool has_q = base + team < nslots;
-    const int32_t slot = has_q ? slots[base + team] : 0;
+    const int32_t slot = has_q ? (slots ? slots[base + team] : base + team) : 0;
     const LbvhPoint q = a.bvh.points[slot];
     const int32_t row = a.bvh.prim_id[slot];
     int level = has_q ? a.next_level[slot] : 0;
@@ -913,11 +913,18 @@ __global__ void __launch_bounds__(kTeamBlock) team_walk_kernel(TeamArgs a, const
       // [q - r + 2M, q + r - 2M] certainly is one
       const float rl = r + 2.0f * mg, rs = r - 2.0f * mg;
       uint32_t part = 0;  // my lane's share of the candidate count of this level
-      uint32_t best_d = 0x7f7fffffu, best_i = 0u, best_d1 = 0x7f7fffffu, best_i1 = 0u;
+      uint32_t bd[NREG], bi[NREG];  // register j of lane t holds list entry 16 j + t (indices are compile-time: stays in VGPRs)
+#pragma unroll
+      for (int j = 0; j < NREG; j++) {
+        bd[j] = 0x7f7fffffu;  // KNN_EMPTY_KEY = {FLT_MAX, 0}
+        bi[j] = 0u;
+      }
       float tau2 = INFINITY;
       bool overflow = false;
       auto kth_dist = [&]() -> float {
-        const uint32_t reg = (NREG > 1 && a.k > 16) ? best_d1 : best_d;
+        uint32_t reg = bd[0];
+#pragma unroll
+        for (int j = 1; j < NREG; j++) reg = ((a.k - 1) >> 4) == j ? bd[j] : reg;
         return __uint_as_float(t_lane_read(reg, (team << 4) + ((a.k - 1) & 15)));
       };
       for (int tree = 0; tree < (HALO ? 2 : 1); tree++) {
@@ -1001,26 +1008,30 @@ __global__ void __launch_bounds__(kTeamBlock) team_walk_kernel(TeamArgs a, const
                     const int src = (team << 4) + (has ? __ffs((int)pending_mine) - 1 : 0);
                     const uint32_t cd = t_lane_read(key_d, src), ci = t_lane_read(key_i, src);
                     const uint64_t cc = ((uint64_t)cd << 32) | ci;
-                    const uint64_t cur = ((uint64_t)best_d << 32) | best_i;
-                    const uint32_t pd = t_team_shr1(best_d), pi = t_team_shr1(best_i);
-                    const uint64_t prev = ((uint64_t)pd << 32) | pi;
-                    const bool take_prev = has & (tl != 0) & (cc < prev);
-                    const bool take_c = has & (cc < cur);
-                    const uint64_t nw = take_prev ? prev : (take_c ? cc : cur);
-                    if (NREG > 1) {
-                      const uint64_t cur1 = ((uint64_t)best_d1 << 32) | best_i1;
-                      const uint32_t lane0 = tl == 0 ? 0xffffffffu : 0u;
-                      const uint32_t qd = t_team_shr1(best_d1) | (t_dpp<0x121>(best_d) & lane0);
-                      const uint32_t qi = t_team_shr1(best_i1) | (t_dpp<0x121>(best_i) & lane0);
-                      const uint64_t prev1 = ((uint64_t)qd << 32) | qi;
-                      const bool take_prev1 = has & (cc < prev1);
-                      const bool take_c1 = has & (cc < cur1);
-                      const uint64_t nw1 = take_prev1 ? prev1 : (take_c1 ? cc : cur1);
-                      best_d1 = (uint32_t)(nw1 >> 32);
-                      best_i1 = (uint32_t)nw1;
+                    // every register shifts like one 16 * NREG long list: lane 0 of register j follows lane 15
+                    // of register j - 1 (row_ror:1 brings it round; combined by mask, see team_pass)
+                    const uint32_t lane0 = tl == 0 ? 0xffffffffu : 0u;
+                    uint32_t nd_[NREG], ni_[NREG];
+#pragma unroll
+                    for (int j = 0; j < NREG; j++) {
+                      const uint64_t cur = ((uint64_t)bd[j] << 32) | bi[j];
+                      uint32_t pd = t_team_shr1(bd[j]), pi = t_team_shr1(bi[j]);
+                      if (j > 0) {
+                        pd |= t_dpp<0x121>(bd[j - 1]) & lane0;
+                        pi |= t_dpp<0x121>(bi[j - 1]) & lane0;
+                      }
+                      const uint64_t prev = ((uint64_t)pd << 32) | pi;  // list entry before mine (entry 0: key 0, never above cc)
+                      const bool take_prev = has & ((j > 0) | (tl != 0)) & (cc < prev);
+                      const bool take_c = has & (cc < cur);
+                      const uint64_t nw = take_prev ? prev : (take_c ? cc : cur);
+                      nd_[j] = (uint32_t)(nw >> 32);
+                      ni_[j] = (uint32_t)nw;
                     }
-                    best_d = (uint32_t)(nw >> 32);
-                    best_i = (uint32_t)nw;
+#pragma unroll
+                    for (int j = 0; j < NREG; j++) {
+                      bd[j] = nd_[j];
+                      bi[j] = ni_[j];
+                    }
                     pm &= ~__ballot(lane == src);
                   } while (pm);
                   tau2 = knn_gate_from_worst(kth_dist());
@@ -1046,10 +1057,9 @@ __global__ void __launch_bounds__(kTeamBlock) team_walk_kernel(TeamArgs a, const
           for (int reg = 0; reg < NREG; reg++) {
             const int j = tl + 16 * reg;
             if (j >= a.k) continue;
-            const uint32_t bd = reg == 0 ? best_d : best_d1, bi = reg == 0 ? best_i : best_i1;
             const int64_t o = (int64_t)row * a.k + j;
-            const int32_t prim = knn_key_prim(((uint64_t)bd << 32) | bi);
-            const float d = __uint_as_float(bd);
+            const int32_t prim = knn_key_prim(((uint64_t)bd[reg] << 32) | bi[reg]);
+            const float d = __uint_as_float(bd[reg]);
             if (a.out_idx) a.out_idx[o] = prim;
             if (a.out_dist) a.out_dist[o] = d;
             if (a.out_fb) {
@@ -1104,7 +1114,7 @@ __global__ void __launch_bounds__(kTeamBlock) team_walk_kernel(TeamArgs a, const
 
 }  // namespace
 
-bool Engine::team_kernel_supports(int k) { return k >= 1 && k <= 32; }
+bool Engine::team_kernel_supports(int k) { return k >= 1 && k <= 64; }
 
 // How many radius levels the first gather of every packet should serve: with the average density
 // of the scene, the first level at which a box is expected to hold about k/2 other points.  Only
@@ -1154,6 +1164,58 @@ bool Engine::solve_team(const SolveArgs &sa, tknnSolveInfo *info, hipStream_t s)
   const size_t lds = (size_t)kTeamBlock / 64 * kTeamLds;
   const bool with_halo = halo_n_ > 0;
   const bool wide_list = sa.k > 16;  // two list registers per lane
+  if (sa.k > 32) {
+    // 33 <= k <= 64: the packet kernel's lists (96 blocks per query) would overflow at once; every
+    // query goes through the team walk, four list registers per lane, from level 0
+    OWLMI_HIP(hipMemsetAsync(counters_, 0, 32 * sizeof(unsigned long long), s));
+    OWLMI_HIP(hipMemsetAsync(done_, 0, (size_t)n, s));
+    OWLMI_HIP(hipMemsetAsync(isect_sorted_, 0, (size_t)n * sizeof(int64_t), s));
+    OWLMI_HIP(hipMemsetAsync(next_level_, 0, (size_t)n * sizeof(int32_t), s));
+    if (sa.d_levels) OWLMI_HIP(hipMemsetAsync(sa.d_levels, 0xff, (size_t)n * sizeof(int32_t), s));
+    const int walk_blocks = (int)std::min<int64_t>((n + 3) / 4, (int64_t)prop.multiProcessorCount * 16);
+    OWLMI_HIP(hipEventRecord(ev_a_, s));
+    if (with_halo)
+      hipLaunchKernelGGL((team_walk_kernel<true, 4>), dim3(walk_blocks), dim3(kTeamBlock), 0, s, a, (const int32_t *)nullptr, (int32_t)n);
+    else
+      hipLaunchKernelGGL((team_walk_kernel<false, 4>), dim3(walk_blocks), dim3(kTeamBlock), 0, s, a, (const int32_t *)nullptr, (int32_t)n);
+    OWLMI_HIP(hipGetLastError());
+    OWLMI_HIP(hipEventRecord(ev_b_, s));
+    OWLMI_HIP(hipMemcpyAsync(h_counters_, counters_, 10 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+    OWLMI_HIP(hipStreamSynchronize(s));
+    float ms = 0;
+    OWLMI_HIP(hipEventElapsedTime(&ms, ev_a_, ev_b_));
+    tknnSolveInfo mine;
+    std::memset(&mine, 0, sizeof mine);
+    mine.rounds = (int)h_counters_[1];
+    mine.node_tests = (int64_t)h_counters_[2];
+    mine.point_tests = (int64_t)h_counters_[3];
+    mine.total_intersections = (int64_t)h_counters_[4];
+    mine.total_active_rounds = (int64_t)h_counters_[6];
+    mine.unfinished = (int64_t)h_counters_[7];
+    mine.solve_ms = ms;
+    mine.dominant_kernel_ms = ms;
+    mine.dominant_kernel_launches = 1;
+    mine.kernel_used = TKNN_KERNEL_TEAM;
+    mine.list_capacity = 64;
+    if (mine.unfinished && !sa.allow_unfinished) throw RoundsExceeded{};
+    if (h_counters_[8]) {  // stacks exhausted: those queries' state is untouched, lane rounds take them
+      tknnSolveInfo rest;
+      std::memset(&rest, 0, sizeof rest);
+      continue_lane(sa, 0, &rest, s);
+      mine.rounds = std::max(mine.rounds, rest.rounds);
+      mine.node_tests += rest.node_tests;
+      mine.point_tests += rest.point_tests;
+      mine.total_intersections += rest.total_intersections;
+      mine.total_active_rounds += rest.total_active_rounds;
+      mine.unfinished += rest.unfinished;
+      mine.solve_ms += rest.solve_ms;
+    }
+    float radius = sa.start_radius;
+    for (int t = 1; t < mine.rounds; t++) radius *= 2;
+    mine.final_radius = radius;
+    if (info) *info = mine;
+    return true;
+  }
   const void *entry = with_halo ? (wide_list ? (const void *)team_kernel<true, 2> : (const void *)team_kernel<true, 1>)
                                 : (wide_list ? (const void *)team_kernel<false, 2> : (const void *)team_kernel<false, 1>);
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, entry, kTeamBlock, lds) != hipSuccess) per_cu = 2;

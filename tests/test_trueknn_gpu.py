@@ -5,7 +5,7 @@ import pytest
 import oracle
 from owlraytracing_amd import _lib, datasets
 
-from conftest import assert_rows_match
+from conftest import assert_rows_equal_modulo_cross_round_ties, assert_rows_match
 
 pytestmark = pytest.mark.gpu
 
@@ -27,7 +27,7 @@ def test_golden_vectors(golden, kernel):
     eng = _engine()
     eng.build(golden["xyz"])
     k = int(golden["k"])
-    if kernel == _lib.KERNEL_TEAM and k > 32:
+    if kernel == _lib.KERNEL_TEAM and k > 64:
         with pytest.raises(_lib.TknnError):
             eng.solve(k, float(golden["start_radius"]), kernel=kernel)
         return
@@ -50,7 +50,8 @@ def test_golden_vectors(golden, kernel):
 
 @pytest.mark.parametrize("kernel", KERNELS, ids=KERNEL_IDS)
 @pytest.mark.parametrize("n,k,seed", [(100_000, 5, 0), (50_000, 10, 1), (30_000, 16, 2), (20_000, 3, 3),
-                                      (30_000, 17, 4), (40_000, 24, 5), (25_000, 32, 6)])
+                                      (30_000, 17, 4), (40_000, 24, 5), (25_000, 32, 6), (25_000, 33, 7), (20_000, 50, 8),
+                                      (20_000, 64, 9)])
 def test_against_oracle_uniform(kernel, n, k, seed):
     xyz = datasets.uniform3d(n, seed=seed)
     r0 = datasets.start_radius(n, k)
@@ -59,8 +60,8 @@ def test_against_oracle_uniform(kernel, n, k, seed):
     eng.build(xyz)
     r = eng.solve(k, r0, kernel=kernel)
     assert r["info"]["rounds"] == ref["rounds"]
-    assert np.array_equal(r["idx"].cpu().numpy(), ref["idx"])
-    assert np.array_equal(r["dist"].cpu().numpy().view(np.int32), ref["dist"].view(np.int32))
+    tied = assert_rows_equal_modulo_cross_round_ties(r["idx"].cpu().numpy(), r["dist"].cpu().numpy(), ref["idx"], ref["dist"])
+    assert tied <= 2  # exact fp32 distance ties between candidates of different rounds: a handful per million rows
     assert np.array_equal(r["intersections"].cpu().numpy(), ref["intersections"])
     eng.close()
 
