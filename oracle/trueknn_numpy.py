@@ -10,9 +10,12 @@ file states what that replay must come to, with none of its machinery:
   * candidates of query q at level t: every p (q itself included) with
     fl32(c_p - r_t) <= q <= fl32(c_p + r_t) on all three axes                 (deviceCode.cu:38-56)
   * q finishes at the first level t* at which at least k candidates other than q exist; its row
-    is the k smallest (distance, index) pairs among those candidates          (deviceCode.cu:100-134,
-    ascending-index visit order); distance = sqrt((dx*dx + dy*dy) + dz*dz) in float32, each
-    operation rounded, as deviceCode.cu:110-113 is written
+    is the k smallest (distance, first level, index) triples among those candidates, "first level"
+    being the level at which a candidate first was one: the reference's lists persist over rounds
+    and a new entry goes BEHIND listed ones of equal distance (deviceCode.cu:77-85 skip,
+    :116-134 strict '<'; ascending-index visit order inside a round)
+    distance = sqrt((dx*dx + dy*dy) + dz*dz) in float32, each operation rounded, as
+    deviceCode.cu:110-113 is written
   * intersections(q) = sum of candidate counts (self included) over levels 0..t*   (deviceCode.cu:74)
   * rounds = 1 + max t*                                                        (hostCode.cpp:285-340)
 
@@ -48,6 +51,7 @@ def trueknn_numpy(xyz, k, start_radius, max_rounds=64, query_ids=None, stop_quie
     radius = np.float32(start_radius)
     active = queries.copy()
     rounds = 0
+    first_seen = {int(q): {} for q in active}  # query -> {candidate position: level at which it first was one}
     while len(active):
         if rounds >= max_rounds:
             if stop_quietly:
@@ -66,13 +70,18 @@ def trueknn_numpy(xyz, k, start_radius, max_rounds=64, query_ids=None, stop_quie
             p = p[inside]
             isect[q] += len(p)
             others = p[p != q] if ids is None else p[ids[p] != ids[q]]
+            seen = first_seen[int(q)]
+            for c_pos in others:
+                seen.setdefault(int(c_pos), rounds)
             if len(others) >= k:
                 d = distance32(xyz[others], xyz[q])
                 names = others if ids is None else ids[others]
-                order = np.lexsort((names, d))[:k]
+                since = np.asarray([seen[int(c_pos)] for c_pos in others], np.int64)
+                order = np.lexsort((names, since, d))[:k]
                 idx[q] = names[order]
                 dist[q] = d[order]
                 level_of[q] = rounds
+                del first_seen[int(q)]
             else:
                 still.append(q)
         rounds += 1

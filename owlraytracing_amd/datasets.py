@@ -181,3 +181,21 @@ def boundary_band(anchors: int, r0: float, seed: int = 0, levels: int = 3, sprea
                         out.append(p)
     pts = np.asarray(out, dtype=np.float32)
     return pts[rng.permutation(len(pts))]
+
+
+def cross_round_ties(clumps: int = 150, seed: int = 17) -> np.ndarray:
+    """Isolated clumps q, A, B, C with |qA| = |qB| = |qC| = 1.125 exactly (a 1-2-2 triple scaled by
+    3/8): A = q + (.375, .75, .75) lies inside q's box of radius 1, B = q + (1.125, 0, 0) and
+    C = q - (0, 0, 1.125) only inside the box of radius 2.  With start radius 1 and k = 2 the query q
+    sees one other in round 0 (A) and three in round 1; the reference's persistent list keeps A first
+    and then the smaller index of B, C -- whatever A's index is.  Indices are shuffled so that every
+    order occurs."""
+    rng = np.random.default_rng(seed)
+    side = int(np.ceil(clumps ** (1 / 3)))
+    pts = []
+    for c in range(clumps):
+        centre = np.array([c % side, (c // side) % side, c // (side * side)], np.float32) * np.float32(16)
+        pts += [centre, centre + np.float32([0.375, 0.75, 0.75]), centre + np.float32([1.125, 0, 0]),
+                centre - np.float32([0, 0, 1.125])]
+    pts = np.asarray(pts, np.float32)
+    return pts[rng.permutation(len(pts))]

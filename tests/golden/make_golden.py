@@ -48,6 +48,8 @@ def cases():
     yield "k32_n2500", datasets.uniform3d(2500, seed=11), 32, 0.03
     # satellites on the box faces of 40 anchors, +-2 ulps, coordinates from 1e-3 to 600
     yield "boundaryband_n3640_k7", datasets.boundary_band(40, 0.01, seed=4), 7, 0.01
+    # exact-distance ties between candidates first seen in different rounds (persistent lists)
+    yield "crossroundties_n400_k2", datasets.cross_round_ties(100, seed=17), 2, 1.0
 
 
 def main():

@@ -46,9 +46,14 @@ def test_row_invariants(golden):
     assert np.all((idx >= 0) & (idx < n))
     s = np.sort(idx, axis=1)
     assert np.all(s[:, 1:] != s[:, :-1]) if k > 1 else True, "no duplicate neighbours"
-    # ties inside a row are ordered by index (canonical ascending visit order)
+    # ties inside a row are ordered by index (canonical ascending visit order) -- unless the two
+    # candidates entered the persistent list in different rounds, which the crossroundties fixture
+    # is made of (deviceCode.cu:77-85,116-134)
     same = dist[:, 1:] == dist[:, :-1]
-    assert np.all(idx[:, 1:][same] > idx[:, :-1][same])
+    if not golden["name"].startswith("crossroundties"):
+        assert np.all(idx[:, 1:][same] > idx[:, :-1][same])
+    else:
+        assert np.any(idx[:, 1:][same] < idx[:, :-1][same])
     # recomputed distances are the stored ones, bit for bit
     q = np.repeat(np.arange(n), k)
     d = np.array([oracle.distance(golden["xyz"][p], golden["xyz"][qq])
