@@ -16,3 +16,12 @@ def test_randomised_parity_sweep():
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     last = r.stdout.strip().splitlines()[-1]
     assert last.startswith("fuzz:") and int(last.split()[1]) >= 10, last
+
+
+@pytest.mark.gpu
+def test_randomised_dbscan_sweep():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "fuzz_dbscan.py"), "15", "5"], capture_output=True,
+                       text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    last = r.stdout.strip().splitlines()[-1]
+    assert last.startswith("fuzz:") and int(last.split()[1]) >= 3, last
