@@ -89,6 +89,11 @@ def main():
     if args.gpus != world:
         if world == 1 and args.gpus > 1:
             raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d" % (args.gpus, args.gpus))
+    # TKNN_BENCH_BACKEND=gloo: rehearsal of the N > 1 path with the ranks sharing the GPUs there are
+    # (messages staged through the host); the driver's runs use nccl = RCCL, one rank per GPU
+    backend = os.environ.get("TKNN_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank %= max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
@@ -105,7 +110,10 @@ def main():
                 os.environ.setdefault("MASTER_PORT", "29577")
                 os.environ.setdefault("RANK", "0")
                 os.environ.setdefault("WORLD_SIZE", "1")
-            dist.init_process_group("nccl", device_id=dev)
+            if backend == "nccl":
+                dist.init_process_group("nccl", device_id=dev)
+            else:
+                dist.init_process_group(backend)
         n_total = n * world
         r0 = datasets.start_radius(n_total, k)
         solver = tkd.ShardedTrueKNN(dev, kernel=args.kernel)
