@@ -71,8 +71,29 @@ def main():
                 assert_rows_equal_modulo_cross_round_ties(r["idx"].cpu().numpy(), r["dist"].cpu().numpy(), ref["idx"], ref["dist"])
             except AssertionError as e:
                 raise AssertionError(tag + ": " + str(e))
+        halo_note = ""
+        if rng.random() < 0.35 and n > 4 * (k + 2):
+            # the sharded layout: queries = the points on one side of a random plane (own tree, global
+            # ids), the rest as the halo tree every query also searches
+            axis, cut = int(rng.integers(0, 3)), float(np.quantile(xyz[:, int(rng.integers(0, 3))], rng.uniform(0.3, 0.7)))
+            own = np.nonzero(xyz[:, axis] <= cut)[0].astype(np.int32)
+            rest = np.nonzero(xyz[:, axis] > cut)[0].astype(np.int32)
+            if len(own) > k + 1 and len(rest) > 0:
+                sub = oracle.trueknn(xyz, k, r0, query_ids=own, max_rounds=64)
+                eng.build(xyz[own], own)
+                eng.set_halo(xyz[rest], rest)
+                for kern in (_lib.KERNEL_TEAM, _lib.KERNEL_WAVE, _lib.KERNEL_LANE):
+                    r = eng.solve(k, r0, kernel=kern)
+                    tag = "halo %s n=%d own=%d k=%d r0=%g kernel=%d" % (name, n, len(own), k, r0, kern)
+                    assert np.array_equal(r["intersections"].cpu().numpy(), sub["intersections"][own]), tag
+                    try:
+                        assert_rows_equal_modulo_cross_round_ties(r["idx"].cpu().numpy(), r["dist"].cpu().numpy(), sub["idx"][own], sub["dist"][own])
+                    except AssertionError as e:
+                        raise AssertionError(tag + ": " + str(e))
+                eng.set_halo(None, None)
+                halo_note = " +halo(own=%d)" % len(own)
         cases += 1
-        print("ok %-10s n=%6d k=%2d r0=%-10.4g rounds=%2d mean_isect=%.1f" % (name, n, k, r0, ref["rounds"], ref["intersections"].mean()), flush=True)
+        print("ok %-10s n=%6d k=%2d r0=%-10.4g rounds=%2d mean_isect=%.1f%s" % (name, n, k, r0, ref["rounds"], ref["intersections"].mean(), halo_note), flush=True)
     print("fuzz: %d cases x 3 kernels agree with the checker in %.0f s" % (cases, time.time() - t0))
 
 
