@@ -166,13 +166,14 @@ def main():
     kernel_name = {1: "lane_round_kernel", 2: "wave_packet_kernel", 3: "team_kernel"}.get(int(info["kernel_used"]), "?")
     # HBM traffic from the PMC counters is collected in separate rocprofv3 passes (profiles/);
     # attach the committed per-launch figure when it was measured for this exact workload.
-    traffic = None
+    traffic, issue = None, {}
     tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
     if os.path.exists(tpath):
         try:
             rec = json.load(open(tpath)).get("%s:n=%d:k=%d" % (kernel_name, n_local, k))
             if rec:
                 traffic = rec["bytes_per_launch"]
+                issue = {k2: rec[k2] for k2 in ("valu_wave_instructions_per_launch", "salu_wave_instructions_per_launch") if k2 in rec}
         except Exception:
             traffic = None
 
@@ -217,6 +218,20 @@ def main():
             "timing": "HIP events on the launch stream, recorded inside libowl_mi355x.so around the kernel",
         },
     }
+    if issue.get("valu_wave_instructions_per_launch"):
+        # the bound that actually binds: vector instruction issue.  Instruction counts come
+        # from the committed rocprofv3 PMC pass of this workload, the time is this run's; a wave64 VALU
+        # instruction occupies its SIMD for 4 cycles, 4 SIMDs per CU.
+        props = torch.cuda.get_device_properties(dev)
+        clock_hz = float(getattr(props, "clock_rate", 2400000)) * 1e3
+        simds = props.multi_processor_count * 4
+        line["roofline"]["issue"] = {
+            "valu_wave_instructions_per_launch": issue["valu_wave_instructions_per_launch"],
+            "salu_wave_instructions_per_launch": issue.get("salu_wave_instructions_per_launch"),
+            "valu_busy_frac": issue["valu_wave_instructions_per_launch"] * 4.0 / (simds * clock_hz * kern_ms * 1e-3),
+            "clock_mhz": clock_hz / 1e6,
+            "source": "profiles/hbm_traffic.json (rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU on this workload)",
+        }
     if not sharded:
         line["build_ms"] = float(build_info["build_ms"])
         line["tree_bytes"] = int(build_info["device_bytes"])

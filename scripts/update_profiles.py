@@ -33,6 +33,9 @@ def main():
     d[key]["FETCH_SIZE_KB_per_launch"] = fetch_kb
     d[key]["WRITE_SIZE_KB_per_launch"] = write_kb
     d[key]["uncorrected_bytes_per_launch"] = int((fetch_kb + write_kb) * 1024)
+    d[key]["valu_wave_instructions_per_launch"] = val("SQ_INSTS_VALU")
+    d[key]["salu_wave_instructions_per_launch"] = val("SQ_INSTS_SALU")
+    d[key]["gui_active_cycles_per_launch"] = val("GRBM_GUI_ACTIVE")  # summed over the 8 XCDs
     json.dump(d, open(p, "w"), indent=1)
     b = json.load(open(bench))
     print("bench: %.3g q/s, %.2f ms/step, kernel %.2f ms; VALU %.3g SALU %.3g per launch; traffic %.2f GB" % (
