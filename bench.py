@@ -43,7 +43,7 @@ def cpu_baseline(xyz, k, r0, seconds_budget=25.0):
     n = len(xyz)
     threads = oracle.num_threads()
     rng = np.random.default_rng(7)
-    sample = 400_000
+    sample = 2_000_000  # ~10 s of CPU work on the GPU box: bounded, but long enough to average out scheduling noise
     q = np.sort(rng.choice(n, sample, replace=False)).astype(np.int32)
     t0 = time.perf_counter()
     ref = oracle.trueknn(xyz, k, r0, query_ids=q)
