@@ -81,6 +81,12 @@ typedef struct {
   int32_t kernel_used;         /* TKNN_KERNEL_*                                                   */
   int32_t list_capacity;       /* register k-list size the kernel was instantiated with           */
   int64_t unfinished;          /* queries left without k neighbours (only with allow_unfinished)  */
+  int64_t tie_rows;            /* rows with bit-identical fp32 distances among their k + 1 best,   */
+                               /* redone in the reference's tie order (first round, then index;    */
+                               /* deviceCode.cu:77-85: lists persist over rounds)                  */
+  int64_t tie_rows_left;       /* ... of which kept (dist, index) order: walk stack exhausted     */
+  float tie_ms;                /* device time of that pass (included in solve_ms)                 */
+  int32_t reserved_;
 } tknnSolveInfo;
 
 typedef struct {

@@ -34,6 +34,10 @@ class SolveInfo(ctypes.Structure):
         ("kernel_used", ctypes.c_int32),
         ("list_capacity", ctypes.c_int32),
         ("unfinished", ctypes.c_int64),
+        ("tie_rows", ctypes.c_int64),
+        ("tie_rows_left", ctypes.c_int64),
+        ("tie_ms", ctypes.c_float),
+        ("reserved_", ctypes.c_int32),
     ]
 
     def as_dict(self):

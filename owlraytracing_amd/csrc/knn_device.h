@@ -41,24 +41,61 @@ __device__ __forceinline__ int32_t knn_key_prim(uint64_t key) {
   return key == KNN_EMPTY_KEY ? -1 : (int32_t)(uint32_t)key;
 }
 
+// Rows whose order depends on how bit-identical distances are ordered (KList::has_ties below) are
+// flagged by whichever kernel finishes them and redone by tie_fix_kernel (trueknn_team.hip):
+// tie[slot] = 1 + the level the query finished at, counters[kTieCounter] counts them, and the first
+// kTieListCap slots are also listed so that the usual handful needs no compaction pass.
+// counters[kTieCounter + 1]: tie_fix_kernel's work cursor, [kTieCounter + 2]: rows it had to leave.
+constexpr int kTieCounter = 32;  // no kernel's own counter reset reaches this far
+constexpr int kCounters = 40;
+constexpr int kTieListCap = 4096;
+__device__ __forceinline__ void knn_flag_tie(uint8_t *tie, int32_t *tie_list, unsigned long long *counters, int32_t slot, int level) {
+  if (level >= 255) return;
+  tie[slot] = (uint8_t)(1 + level);
+  const unsigned long long pos = atomicAdd(&counters[kTieCounter], 1ull);
+  if (pos < (unsigned long long)kTieListCap) tie_list[pos] = slot;
+}
+
 template <int K>
 struct KList {
   uint64_t key[K];
+  // smallest distance (bits; distances are >= 0, so bits order like values) among the candidates this
+  // list had no room for: equals the last entry's distance iff a candidate tied with it stayed out
+  uint32_t left_out;
   __device__ __forceinline__ void clear() {
 #pragma unroll
     for (int j = 0; j < K; j++) key[j] = KNN_EMPTY_KEY;
+    left_out = 0xffffffffu;
   }
   __device__ __forceinline__ uint64_t worst() const { return key[K - 1]; }
   // sorted insert, fully unrolled so the list stays in VGPRs (no dynamic indexing)
   __device__ __forceinline__ void insert(uint64_t c) {
     if (c < key[K - 1]) {
+      const uint32_t out = (uint32_t)(key[K - 1] >> 32);
+      left_out = out < left_out ? out : left_out;
 #pragma unroll
       for (int j = K - 1; j > 0; --j) {
         bool shift = c < key[j - 1];
         key[j] = shift ? key[j - 1] : (c < key[j] ? c : key[j]);
       }
       key[0] = c < key[0] ? c : key[0];
+    } else {
+      const uint32_t out = (uint32_t)(c >> 32);
+      left_out = out < left_out ? out : left_out;
     }
+  }
+  // Does the row of the first k entries depend on how bit-identical fp32 distances are ordered?
+  // True if two of entries 0..k have the same distance (entry k: the best candidate left out of the
+  // row).  The reference orders such keys by the round in which each was first a candidate
+  // (deviceCode.cu:77-85 keeps what is listed), the lists here by index: flagged rows are redone by
+  // tie_fix_kernel (trueknn_team.hip).  False positives are harmless.  Candidates the callers drop
+  // at their gates are strictly farther than the k-th entry (knn_gate_from_worst) and never tie.
+  __device__ __forceinline__ bool has_ties(int k) const {
+    bool t = false;
+#pragma unroll
+    for (int j = 1; j < K; j++) t |= (j <= k) & ((uint32_t)(key[j] >> 32) == (uint32_t)(key[j - 1] >> 32));
+    t |= (k >= K) & (left_out == (uint32_t)(key[K - 1] >> 32));
+    return t;
   }
 };
 

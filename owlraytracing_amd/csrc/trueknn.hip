@@ -30,6 +30,8 @@ struct LaneRoundArgs {
   float radius;
   int k;
   uint8_t *done;           // per sorted slot
+  uint8_t *tie;            // per sorted slot: 1 + level for rows finished with exact-distance ties (knn_flag_tie)
+  int32_t *tie_list;
   const int32_t *next_level;  // per sorted slot: first level this query takes part in (may be null)
   int64_t *isect_sorted;   // per sorted slot, accumulated over rounds
   int32_t *out_idx;        // n*k, caller order (may be null)
@@ -151,6 +153,7 @@ __global__ void __launch_bounds__(kLaneBlock) lane_round_kernel(LaneRoundArgs a)
     if (finished) {
       a.done[t] = 1;
       write_row<K>(a, bvh.prim_id[t], list, isect);
+      if (list.has_ties(a.k)) knn_flag_tie(a.tie, a.tie_list, a.counters, t, a.level);
     }
   }
   // wave-aggregated counters (all 64 lanes are here)
@@ -271,7 +274,8 @@ Engine::Engine() {
   OWLMI_HIP(hipGetDevice(&device_));
   OWLMI_HIP(hipEventCreate(&ev_a_));
   OWLMI_HIP(hipEventCreate(&ev_b_));
-  OWLMI_HIP(hipMalloc((void **)&counters_, 32 * sizeof(unsigned long long)));  // [16..23]: the team kernel's per-XCD packet counters
+  OWLMI_HIP(hipMalloc((void **)&counters_, kCounters * sizeof(unsigned long long)));  // [16..23]: the team kernel's per-XCD packet counters; [32]: tie rows
+  OWLMI_HIP(hipMalloc((void **)&tie_list_, kTieListCap * sizeof(int32_t)));
   OWLMI_HIP(hipHostMalloc((void **)&h_counters_, 16 * sizeof(unsigned long long)));
   if (const char *e = getenv("TKNN_LEAF_MAX")) {
     int v = atoi(e);
@@ -283,6 +287,8 @@ Engine::~Engine() {
   if (done_) (void)hipFree(done_);
   if (isect_sorted_) (void)hipFree(isect_sorted_);
   if (next_level_) (void)hipFree(next_level_);
+  if (tie_) (void)hipFree(tie_);
+  if (tie_list_) (void)hipFree(tie_list_);
   if (counters_) (void)hipFree(counters_);
   if (halo_mask_) (void)hipFree(halo_mask_);
   if (slot_list_) (void)hipFree(slot_list_);
@@ -316,12 +322,15 @@ void Engine::build(const float *d_xyz, const int32_t *d_ids, int64_t n, tknnBuil
     if (done_) (void)hipFree(done_);
     if (isect_sorted_) (void)hipFree(isect_sorted_);
     if (next_level_) (void)hipFree(next_level_);
+    if (tie_) (void)hipFree(tie_);
+    tie_ = nullptr;
     done_ = nullptr;
     isect_sorted_ = nullptr;
     next_level_ = nullptr;
     OWLMI_HIP(hipMalloc((void **)&done_, (size_t)n));
     OWLMI_HIP(hipMalloc((void **)&isect_sorted_, (size_t)n * sizeof(int64_t)));
     OWLMI_HIP(hipMalloc((void **)&next_level_, (size_t)n * sizeof(int32_t)));
+    OWLMI_HIP(hipMalloc((void **)&tie_, (size_t)n));
     state_cap_ = n;
   }
   OWLMI_HIP(hipMemcpyAsync(scene_, bvh_.scene_device(), 6 * sizeof(float), hipMemcpyDeviceToHost, s));
@@ -372,6 +381,8 @@ void Engine::lane_rounds(const SolveArgs &sa, int first_level, bool fresh, tknnS
   a.out_level = sa.d_levels;
   a.k = sa.k;
   a.done = done_;
+  a.tie = tie_;
+  a.tie_list = tie_list_;
   a.isect_sorted = isect_sorted_;
   a.next_level = fresh ? nullptr : next_level_;
   a.out_idx = sa.d_idx;
@@ -490,14 +501,26 @@ void Engine::solve(const SolveArgs &sa, int kernel, tknnSolveInfo *info, hipStre
     else
       kernel = wave_kernel_available() ? TKNN_KERNEL_WAVE : TKNN_KERNEL_LANE;
   }
+  // Rows whose order depends on how bit-identical fp32 distances are ordered: every kernel lists by
+  // (dist, index) and flags them in tie_; fix_ties redoes them in the reference's order, by the round in
+  // which each neighbour was first a candidate (deviceCode.cu:77-85 -- lists persist over rounds).
+  OWLMI_HIP(hipMemsetAsync(tie_, 0, (size_t)bvh_.size(), s));
+  OWLMI_HIP(hipMemsetAsync(counters_ + kTieCounter, 0, 3 * sizeof(unsigned long long), s));
+  tknnSolveInfo mine;
+  std::memset(&mine, 0, sizeof mine);
+  bool solved = false;
   if (kernel == TKNN_KERNEL_TEAM) {
-    if (solve_team(sa, info, s)) return;
-    kernel = TKNN_KERNEL_WAVE;  // (solve_team handles its own tail and returns true today)
+    solved = solve_team(sa, &mine, s);
+    if (!solved) kernel = TKNN_KERNEL_WAVE;  // (solve_team handles its own tail and returns true today)
   }
-  if (kernel == TKNN_KERNEL_WAVE)
-    solve_wave(sa, info, s);
-  else
-    solve_lane(sa, info, s);
+  if (!solved) {
+    if (kernel == TKNN_KERNEL_WAVE)
+      solve_wave(sa, &mine, s);
+    else
+      solve_lane(sa, &mine, s);
+  }
+  fix_ties(sa, &mine, s);
+  if (info) *info = mine;
 }
 
 }  // namespace owlmi

@@ -70,6 +70,8 @@ class Engine {
   // trueknn_team.hip; returns false if a packet needed more leaf blocks than the kernel can name
   bool solve_team(const SolveArgs &sa, tknnSolveInfo *info, hipStream_t s);
   static bool team_kernel_supports(int k);
+  // trueknn_team.hip: redo the rows flagged in tie_ with the reference's order of exact-distance ties
+  void fix_ties(const SolveArgs &sa, tknnSolveInfo *info, hipStream_t s);
   int first_step_estimate(const SolveArgs &sa) const;
   float scene_[6] = {0, 0, 0, 0, 0, 0};  // bounds of the built point set (host copy)
 
@@ -80,6 +82,8 @@ class Engine {
   uint8_t *done_ = nullptr;
   int64_t *isect_sorted_ = nullptr;
   int32_t *next_level_ = nullptr;
+  int32_t *tie_list_ = nullptr;  // the first kTieListCap flagged slots, in the order the kernels met them
+  uint8_t *tie_ = nullptr;  // per sorted slot: 0, or 1 + the level at which the query finished with exact-distance ties in reach of its row
   int64_t state_cap_ = 0;
   unsigned long long *counters_ = nullptr, *h_counters_ = nullptr;
   void *wave_ws_ = nullptr;

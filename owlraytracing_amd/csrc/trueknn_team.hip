@@ -98,6 +98,10 @@ struct TeamArgs {
   uint8_t *done;
   int64_t *isect_sorted;
   int32_t *next_level;
+  // per sorted slot: 1 + level for rows that finished with bit-identical distances among entries 0..k of
+  // the list (entry k: the best candidate left out); tie_fix_kernel redoes them in the reference's tie order
+  uint8_t *tie;
+  int32_t *tie_list;
   // [0] (unused here) [16..23] per-XCD packet counters [1] max levels [2] node tests [3] point tests [4] sum isect
   // [5] error flags (1 max_rounds) [6] sum levels [7] unfinished [8] handed over [9] min hand-over level
   unsigned long long *counters;
@@ -207,11 +211,27 @@ struct TeamLds {
   int32_t *qlist;     // compact list of the queries this pass serves
 };
 
+// Can two candidates of one query at the same fp32 distance d have become candidates in DIFFERENT
+// rounds?  A candidate's Chebyshev distance t obeys d / sqrt(3) <= t <= d, and round l takes it iff
+// t <= r_l (up to the rounding margin M of the box test, see team_kernel).  Going up the radii: if
+// d is safely below r_l, every candidate at distance d passes round l -- and none passed an earlier
+// round, or the loop would have stopped there; if not, but d / sqrt(3) can be below r_l, some may
+// pass and others not.  Exact duplicates (d = 0) and the other ties of quantised data mostly are of
+// the first kind and need no second look.  qmax = max |q|, r_last = the radius the query finished with.
+__device__ __forceinline__ bool tie_may_straddle(float d, float r0, float r_last, float qmax) {
+  for (float r = r0;; r = r * 2.0f) {
+    const float mg = (qmax + 2.0f * r) * 4.76837158203125e-07f;  // 2^-21
+    if (d <= (r - mg) * 0.99999f) return false;
+    if (d <= (r + mg) * 1.73206f) return true;  // t >= d / sqrt(3) > r + M otherwise: certainly not a candidate of round l
+    if (!(r < r_last)) return true;  // (a listed candidate passes the last round's test: not reached)
+  }
+}
+
 // One pass of the four teams over a compact list of queries.  SELECT = false: count candidates
 // (deviceCode.cu:74,103).  SELECT = true: also keep the k best (dist,index) keys, lane j of the
 // team holding the j-th, and write the row if the query turns out finished (>= k others).
 // NREG: list registers per lane -- the team's sorted list holds 16 * NREG keys (k <= 16: 1, k <= 32: 2)
-template <bool SELECT, bool HALO, int NREG>
+template <bool SELECT, bool HALO, int NREG, bool FULL>
 __device__ __forceinline__ void team_pass(const TeamArgs &a, const TeamLds &L, int n_list, float r_inner, int m,
                                           const LbvhPoint *own_pts, const LbvhPoint *halo_pts, int lane) {
   const int team = lane >> 4, tl = lane & 15;
@@ -278,6 +298,12 @@ __device__ __forceinline__ void team_pass(const TeamArgs &a, const TeamLds &L, i
     uint32_t cnt = 0;
     uint32_t best_d = 0x7f7fffffu, best_i = 0u;  // KNN_EMPTY_KEY = {FLT_MAX, 0}
     uint32_t best_d1 = 0x7f7fffffu, best_i1 = 0u;  // entries 16..31 (NREG == 2)
+    // k == list size: the smallest distance (bits) among the keys that found no room, tracked in the lane
+    // of the last entry -- equal to the k-th distance iff a candidate tied with the row's last stayed out
+    // (FULL is a template parameter: as a run-time flag the three instructions it adds to an insert
+    // were if-converted into every k's loop, +4 % on the benchmark)
+    constexpr bool full = FULL;
+    uint32_t left_out = 0xffffffffu;
     // the k-th best of my team, whose distance gates further candidates
     auto kth_dist = [&]() -> float {
       const uint32_t reg = (NREG > 1 && a.k > 16) ? best_d1 : best_d;
@@ -324,6 +350,7 @@ __device__ __forceinline__ void team_pass(const TeamArgs &a, const TeamLds &L, i
             const bool take_prev = has & (tl != 0) & (c < prev);
             const bool take_c = has & (c < cur);
             const uint64_t nw = take_prev ? prev : (take_c ? c : cur);
+            if (NREG == 1 && full) left_out = has ? min(left_out, take_c ? best_d : cd) : left_out;
             if (NREG > 1) {
               // second register: its lane 0 follows lane 15 of the first (row_ror:1 brings it round)
               const uint64_t cur1 = ((uint64_t)best_d1 << 32) | best_i1;
@@ -336,6 +363,7 @@ __device__ __forceinline__ void team_pass(const TeamArgs &a, const TeamLds &L, i
               const bool take_prev1 = has & (c < prev1);
               const bool take_c1 = has & (c < cur1);
               const uint64_t nw1 = take_prev1 ? prev1 : (take_c1 ? c : cur1);
+              if (full) left_out = has ? min(left_out, take_c1 ? best_d1 : cd) : left_out;
               best_d1 = (uint32_t)(nw1 >> 32);
               best_i1 = (uint32_t)nw1;
             }
@@ -414,12 +442,31 @@ __device__ __forceinline__ void team_pass(const TeamArgs &a, const TeamLds &L, i
     const uint32_t self = cnt ? 1u : 0u;  // a query lies in its own box, and ids are unique
     const uint32_t others = cnt - self;
     if (!SELECT && m > 1) cnt_i0 = t_team_sum(cnt_i0);
+    uint32_t tied = 0u;
+    if (SELECT) {
+      // entry j against entry j - 1, for j = 1..k (KList::has_ties is the per-lane form of this)
+      bool tie0 = (tl >= 1) & (tl <= a.k) & (best_d == t_team_shr1(best_d)), tie1 = false;
+      if (NREG > 1) {
+        const uint32_t lane0 = tl == 0 ? 0xffffffffu : 0u;
+        const uint32_t before = t_team_shr1(best_d1) | (t_dpp<0x121>(best_d) & lane0);
+        tie1 = (16 + tl <= a.k) & (best_d1 == before);
+        if (full) tie1 |= (tl == 15) & (left_out == best_d1);
+      } else if (full) {
+        tie0 |= (tl == 15) & (left_out == best_d);
+      }
+      if (__ballot(tie0 | tie1) != 0ull) {  // rare: does any of them span two rounds?
+        const float qmax = fmaxf(fmaxf(fabsf(t_qx), fabsf(t_qy)), fabsf(t_qz));
+        tie0 = tie0 && tie_may_straddle(__uint_as_float(best_d), a.start_radius, t_r, qmax);
+        if (NREG > 1) tie1 = tie1 && tie_may_straddle(__uint_as_float(best_d1), a.start_radius, t_r, qmax);
+      }
+      tied = ((uint32_t)(__ballot(tie0 | tie1) >> (team * 16)) & 0xffffu) ? 1u : 0u;
+    }
     if (on && tl == 0) {
       // counts innermost level first; a one-level pass fills slot 0
       uint32_t *out = L.qcnt + qi * 2;
       if (SELECT || m == 1) {
         out[0] = cnt;
-        out[1] = self << 31;
+        out[1] = (self << 31) | (tied << 30);
       } else {
         out[0] = cnt_i0;
         out[1] = cnt | (self << 31);
@@ -453,7 +500,7 @@ __device__ __forceinline__ void team_pass(const TeamArgs &a, const TeamLds &L, i
   }
 }
 
-template <bool HALO, int NREG>
+template <bool HALO, int NREG, bool FULL>
 __global__ void __launch_bounds__(kTeamBlock) __attribute__((amdgpu_waves_per_eu(4))) team_kernel(TeamArgs a) {
   extern __shared__ __align__(16) unsigned char smem[];
   const int lane = threadIdx.x & 63;
@@ -752,7 +799,7 @@ __global__ void __launch_bounds__(kTeamBlock) __attribute__((amdgpu_waves_per_eu
       };
       {
         const int n_count = build_qlist(count_first);
-        if (!(TKNN_DIAG_BUILD && (a.diag & 4))) team_pass<false, HALO, NREG>(a, L, n_count, r_in0, m, own_pts, halo_pts, lane);
+        if (!(TKNN_DIAG_BUILD && (a.diag & 4))) team_pass<false, HALO, NREG, false>(a, L, n_count, r_in0, m, own_pts, halo_pts, lane);
         t_wave_sync();
       }
       PHASE_END(2);
@@ -762,7 +809,7 @@ __global__ void __launch_bounds__(kTeamBlock) __attribute__((amdgpu_waves_per_eu
       if (count_first) {
         c0 = qcnt[lane * 2 + 0];
         const uint32_t w1 = qcnt[lane * 2 + 1];
-        c1 = m > 1 ? (w1 & 0x7fffffffu) : 0u;
+        c1 = m > 1 ? (w1 & 0x3fffffffu) : 0u;
         selfc = w1 >> 31;
         if (c0 - selfc >= (uint32_t)a.k)
           fin_at = 0;
@@ -774,7 +821,7 @@ __global__ void __launch_bounds__(kTeamBlock) __attribute__((amdgpu_waves_per_eu
       {
         t_wave_sync();
         const int n_select = build_qlist(select_now);
-        if (!(TKNN_DIAG_BUILD && (a.diag & 2))) team_pass<true, HALO, NREG>(a, L, n_select, r_in0, 1, own_pts, halo_pts, lane);
+        if (!(TKNN_DIAG_BUILD && (a.diag & 2))) team_pass<true, HALO, NREG, FULL>(a, L, n_select, r_in0, 1, own_pts, halo_pts, lane);
         t_wave_sync();
       }
       PHASE_END(3);
@@ -806,7 +853,9 @@ __global__ void __launch_bounds__(kTeamBlock) __attribute__((amdgpu_waves_per_eu
         my_isect_sum += (unsigned long long)isect;
         if (a.out_isect) a.out_isect[row] = isect;
         if (a.out_fb) a.out_fb[(int64_t)row * a.k].intersections = isect;
-        if (a.out_level) a.out_level[row] = level + (fin_at > 0 ? fin_at : 0);
+        const int fin_level = level + (fin_at > 0 ? fin_at : 0);
+        if (a.out_level) a.out_level[row] = fin_level;
+        if ((qcnt[lane * 2 + 1] >> 30) & 1u) knn_flag_tie(a.tie, a.tie_list, a.counters, slot, fin_level);  // SELECT saw exact-distance ties
       }
       active = active && !finished;
       level += m;
@@ -921,6 +970,8 @@ __global__ void __launch_bounds__(kTeamBlock) team_walk_kernel(TeamArgs a, const
       }
       float tau2 = INFINITY;
       bool overflow = false;
+      const bool full = a.k == 16 * NREG;  // see team_pass
+      uint32_t left_out = 0xffffffffu;
       auto kth_dist = [&]() -> float {
         uint32_t reg = bd[0];
 #pragma unroll
@@ -1024,6 +1075,7 @@ __global__ void __launch_bounds__(kTeamBlock) team_walk_kernel(TeamArgs a, const
                       const bool take_prev = has & ((j > 0) | (tl != 0)) & (cc < prev);
                       const bool take_c = has & (cc < cur);
                       const uint64_t nw = take_prev ? prev : (take_c ? cc : cur);
+                      if (j == NREG - 1 && full) left_out = has ? min(left_out, take_c ? bd[j] : cd) : left_out;
                       nd_[j] = (uint32_t)(nw >> 32);
                       ni_[j] = (uint32_t)nw;
                     }
@@ -1072,9 +1124,21 @@ __global__ void __launch_bounds__(kTeamBlock) team_walk_kernel(TeamArgs a, const
               a.out_fb[o] = ev;
             }
           }
+          bool tie = false;
+          const float qmax = fmaxf(fmaxf(fabsf(q.x), fabsf(q.y)), fabsf(q.z));
+#pragma unroll
+          for (int reg = 0; reg < NREG; reg++) {
+            uint32_t before = t_team_shr1(bd[reg]);
+            if (reg > 0) before |= t_dpp<0x121>(bd[reg - 1]) & (tl == 0 ? 0xffffffffu : 0u);
+            bool t = ((reg > 0) | (tl >= 1)) & (16 * reg + tl <= a.k) & (bd[reg] == before);
+            if (reg == NREG - 1 && full) t |= (tl == 15) & (left_out == bd[reg]);
+            tie |= t && tie_may_straddle(__uint_as_float(bd[reg]), a.start_radius, r, qmax);
+          }
+          const bool tied = ((uint32_t)(__ballot(tie) >> (team * 16)) & 0xffffu) != 0u;
           if (tl == 0) {
             if (a.out_isect) a.out_isect[row] = isect;
             if (a.out_level) a.out_level[row] = level;
+            if (tied) knn_flag_tie(a.tie, a.tie_list, a.counters, slot, level);
             a.done[slot] = 1;
             isect_sum += (unsigned long long)isect;
           }
@@ -1112,9 +1176,297 @@ __global__ void __launch_bounds__(kTeamBlock) team_walk_kernel(TeamArgs a, const
   }
 }
 
+
+// ---- exact-distance ties in the reference's order ---------------------------------------------------
+// The reference's per-query lists persist over the rounds (deviceCode.cu:77-85 skips what is listed
+// already, :116,:125 insert with a strict '<'): of two candidates at bit-identical fp32 distances the
+// one that became a candidate in an EARLIER round stays ahead, whatever its index; inside one round
+// the canonical order is by index (oracle/trueknn_oracle.c, decision 2).  The kernels above list by
+// (dist, index) only -- the age would cost every insert a third key word -- and flag the rows where
+// that can matter (a.tie).  Here a team redoes one flagged row with the full key (dist, first level,
+// index): the first level of a candidate is the first radius of the doubling sequence whose box test
+// it passes (the test is monotone in r).  Only neighbours within the row's k-th distance can be
+// part of the answer, and that distance is already known (it does not depend on the order of ties):
+// the walk prunes with it from the start, so a row costs a few wide nodes and leaf blocks.
+constexpr int kFixStack = 1024;
+
+struct HasTie {
+  __host__ __device__ bool operator()(uint8_t t) const { return t != 0; }
+};
+
+template <bool HALO, int NREG>
+__global__ void __launch_bounds__(kTeamBlock) tie_fix_kernel(TeamArgs a, const int32_t *slots, int32_t nslots) {
+  // nslots < 0: `slots` is the kernels' own list (knn_flag_tie), as long as the device-side count says --
+  // launched without the host knowing whether anything was flagged; nothing was: every wave leaves at once
+  if (nslots < 0) nslots = (int32_t)min(a.counters[kTieCounter], (unsigned long long)kTieListCap);
+  if (nslots == 0) return;
+  __shared__ int32_t stack_mem[4 * kFixStack];
+  __shared__ WalkLevel levels[2][LBVH_WIDE_LEVELS];
+  const int lane = threadIdx.x & 63, team = lane >> 4, tl = lane & 15;
+  int32_t *stack = stack_mem + team * kFixStack;
+  if (lane < 2 * LBVH_WIDE_LEVELS) {
+    const int t = lane / LBVH_WIDE_LEVELS, l = lane % LBVH_WIDE_LEVELS;
+    levels[t][l].boxes = a.wide[t].level[l];
+    levels[t][l].count = a.wide[t].count[l];
+  }
+  t_wave_sync();
+  unsigned int failed = 0;
+  for (;;) {
+    int base = 0;
+    if (lane == 0) base = (int)atomicAdd(&a.counters[kTieCounter + 1], 4ull);
+    base = __builtin_amdgcn_readfirstlane(base);
+    if (base >= nslots) break;
+    const bool active = base + team < nslots;
+    const int32_t slot = active ? slots[base + team] : 0;
+    const LbvhPoint q = a.bvh.points[slot];
+    const int32_t row = a.bvh.prim_id[slot];
+    const int level = active ? (int)a.tie[slot] - 1 : 0;
+    float r = a.start_radius;
+    for (int i = 0; i < level; i++) r = r * 2.0f;
+    const float mg = (fmaxf(fmaxf(fabsf(q.x), fabsf(q.y)), fabsf(q.z)) + 2.0f * r) * 4.76837158203125e-07f;  // 2^-21, as in team_walk_kernel
+    const float in_below = r - mg, in_upto = r + mg;
+    const float rl = r + 2.0f * mg;
+    // key word between distance and index: the level at which the candidate was first one
+    auto first_level = [&](const LbvhPoint &p) -> uint32_t {
+      float rr = a.start_radius;
+      for (int l = 0; l < level; l++) {
+        if (knn_in_box(p.x, p.y, p.z, rr, q.x, q.y, q.z)) return (uint32_t)l;
+        rr = rr * 2.0f;
+      }
+      return (uint32_t)level;
+    };
+    uint32_t bd[NREG], bl[NREG], bi[NREG];
+#pragma unroll
+    for (int j = 0; j < NREG; j++) {
+      bd[j] = 0x7f7fffffu;  // KNN_EMPTY_KEY = {FLT_MAX, 0}
+      bl[j] = 0u;
+      bi[j] = 0u;
+    }
+    auto kth_dist = [&]() -> float {
+      uint32_t reg = bd[0];
+#pragma unroll
+      for (int j = 1; j < NREG; j++) reg = ((a.k - 1) >> 4) == j ? bd[j] : reg;
+      return __uint_as_float(t_lane_read(reg, (team << 4) + ((a.k - 1) & 15)));
+    };
+    // the row's k-th distance, if the caller asked for distances (else the gate closes as the list fills)
+    float tau2 = INFINITY;
+    if (active) {
+      const int64_t last = (int64_t)row * a.k + (a.k - 1);
+      if (a.out_dist)
+        tau2 = knn_gate_from_worst(a.out_dist[last]);
+      else if (a.out_fb)
+        tau2 = knn_gate_from_worst(a.out_fb[last].dist);
+    }
+    bool overflow = false;
+    for (int tree = 0; tree < (HALO ? 2 : 1); tree++) {
+      const LbvhWideView &wv = a.wide[tree];
+      const LbvhView &tv = tree == 0 ? a.bvh : a.halo;
+      if (tv.n <= 0 || wv.levels <= 0) continue;
+      int sp = 0;
+      if (active) {
+        if (tl == 0) stack[0] = (wv.levels << 26) | 0;  // virtual root above the top level
+        sp = 1;
+      }
+      t_wave_sync();
+      while (__ballot(sp > 0) != 0ull) {
+        const bool work = sp > 0;
+        const int32_t e = work ? stack[sp - 1] : (1 << 26);
+        if (work) sp--;
+        const int lvl = (e >> 26) - 1;  // level of the children
+        const int32_t first_child = (e & 0x3ffffff) * 64;
+        const WalkLevel wl = levels[tree][lvl];
+        const int32_t nchild = lvl == wv.levels - 1 ? (first_child == 0 ? wl.count : 0) : wl.count;
+        LbvhBox bx4[4];  // the node's 64 child boxes, all four loads in flight at once
+#pragma unroll
+        for (int chunk = 0; chunk < 4; chunk++) {
+          const int32_t c = first_child + 16 * chunk + tl;
+          bx4[chunk] = LbvhBox{{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
+          if (work && c < nchild) bx4[chunk] = wl.boxes[c];
+        }
+#pragma unroll
+        for (int chunk = 0; chunk < 4; chunk++) {
+          const int32_t c = first_child + 16 * chunk + tl;
+          const bool valid = work && c < nchild;
+          const LbvhBox bx = bx4[chunk];
+          const bool ov = valid & (bx.lo[0] <= q.x + rl) & (bx.hi[0] >= q.x - rl) & (bx.lo[1] <= q.y + rl) &
+                          (bx.hi[1] >= q.y - rl) & (bx.lo[2] <= q.z + rl) & (bx.hi[2] >= q.z - rl);
+          // beyond the gate: nothing in the box can be listed (0.999995: roundings of m2 and of the
+          // points' distance arithmetic, as in team_walk_kernel)
+          const float gx = fmaxf(fmaxf(bx.lo[0] - q.x, q.x - bx.hi[0]), 0.f), gy = fmaxf(fmaxf(bx.lo[1] - q.y, q.y - bx.hi[1]), 0.f),
+                      gz = fmaxf(fmaxf(bx.lo[2] - q.z, q.z - bx.hi[2]), 0.f);
+          const float m2 = (gx * gx + gy * gy) + gz * gz;
+          const bool keep = ov && !(m2 * 0.999995f > tau2);
+          const uint32_t keep_mine = (uint32_t)(__ballot(keep) >> (team * 16)) & 0xffffu;
+          if (lvl > 0) {
+            if (sp + __popc(keep_mine) > kFixStack) {
+              overflow = true;
+            } else {
+              if (keep) stack[sp + __popc(keep_mine & ((1u << tl) - 1u))] = (lvl << 26) | c;
+              sp += __popc(keep_mine);
+            }
+          } else {
+            uint32_t todo = keep_mine;
+            while (__ballot(todo != 0u) != 0ull) {
+              const bool has_b = todo != 0u;
+              const int32_t b = first_child + 16 * chunk + (has_b ? __ffs((int)todo) - 1 : 0);
+              todo &= todo - 1u;
+              LbvhPoint p = {__uint_as_float(0x7fc00000u), 0.f, 0.f, -1};
+              if (has_b) p = tv.points[(int64_t)b * LBVH_BLOCK + tl];
+              const float dx = p.x - q.x, dy = p.y - q.y, dz = p.z - q.z;
+              const float t = has_b ? fmaxf(fmaxf(fabsf(dx), fabsf(dy)), fabsf(dz)) : __uint_as_float(0x7fc00000u);
+              unsigned long long in_m = __ballot(t <= in_below);
+              const unsigned long long maybe_m = __ballot(t <= in_upto) & ~in_m;
+              if (maybe_m) in_m |= maybe_m & __ballot(knn_in_box(p.x, p.y, p.z, r, q.x, q.y, q.z));
+              const float d2 = t_dist2(dx, dy, dz);
+              unsigned long long pm = in_m & __ballot(p.id != q.id) & __ballot(d2 <= tau2);
+              if (pm) {
+                const uint32_t key_d = __float_as_uint(knn_sqrt(d2));
+                const uint32_t key_l = ((pm >> lane) & 1ull) ? first_level(p) : 0u;
+                const uint32_t key_i = (uint32_t)p.id;
+                do {
+                  const uint32_t pending_mine = (uint32_t)(pm >> (team * 16)) & 0xffffu;
+                  const bool has = pending_mine != 0u;
+                  const int src = (team << 4) + (has ? __ffs((int)pending_mine) - 1 : 0);
+                  const uint32_t cd = t_lane_read(key_d, src), cl = t_lane_read(key_l, src), ci = t_lane_read(key_i, src);
+                  const uint64_t chi = ((uint64_t)cd << 32) | cl;
+                  const uint32_t lane0 = tl == 0 ? 0xffffffffu : 0u;
+                  uint32_t nd_[NREG], nl_[NREG], ni_[NREG];
+#pragma unroll
+                  for (int j = 0; j < NREG; j++) {
+                    uint32_t pd = t_team_shr1(bd[j]), pl = t_team_shr1(bl[j]), pi = t_team_shr1(bi[j]);
+                    if (j > 0) {
+                      pd |= t_dpp<0x121>(bd[j - 1]) & lane0;
+                      pl |= t_dpp<0x121>(bl[j - 1]) & lane0;
+                      pi |= t_dpp<0x121>(bi[j - 1]) & lane0;
+                    }
+                    const uint64_t cur_hi = ((uint64_t)bd[j] << 32) | bl[j], prev_hi = ((uint64_t)pd << 32) | pl;
+                    const bool below_cur = (chi < cur_hi) | ((chi == cur_hi) & (ci < bi[j]));
+                    const bool below_prev = (chi < prev_hi) | ((chi == prev_hi) & (ci < pi));
+                    const bool take_prev = has & ((j > 0) | (tl != 0)) & below_prev;  // entry 0 has no entry before it
+                    const bool take_c = has & below_cur;
+                    nd_[j] = take_prev ? pd : (take_c ? cd : bd[j]);
+                    nl_[j] = take_prev ? pl : (take_c ? cl : bl[j]);
+                    ni_[j] = take_prev ? pi : (take_c ? ci : bi[j]);
+                  }
+#pragma unroll
+                  for (int j = 0; j < NREG; j++) {
+                    bd[j] = nd_[j];
+                    bl[j] = nl_[j];
+                    bi[j] = ni_[j];
+                  }
+                  pm &= ~__ballot(lane == src);
+                } while (pm);
+                tau2 = fminf(tau2, knn_gate_from_worst(kth_dist()));
+              }
+            }
+          }
+        }
+        t_wave_sync();
+      }
+    }
+    if (active && overflow) {
+      failed += tl == 0 ? 1u : 0u;  // the row keeps its (dist, index) order; reported in tknnSolveInfo.tie_rows_left
+    } else if (active) {
+#pragma unroll
+      for (int reg = 0; reg < NREG; reg++) {
+        const int j = tl + 16 * reg;
+        if (j >= a.k) continue;
+        const int64_t o = (int64_t)row * a.k + j;
+        const int32_t prim = knn_key_prim(((uint64_t)bd[reg] << 32) | bi[reg]);
+        const float d = __uint_as_float(bd[reg]);
+        if (a.out_idx) a.out_idx[o] = prim;
+        if (a.out_dist) a.out_dist[o] = d;
+        if (a.out_fb) {
+          a.out_fb[o].ind = prim;
+          a.out_fb[o].dist = d;
+        }
+      }
+    }
+  }
+  const unsigned long long fsum = t_wave_sum((unsigned long long)failed);
+  if (lane == 0 && fsum) atomicAdd(&a.counters[kTieCounter + 2], fsum);
+}
+
 }  // namespace
 
 bool Engine::team_kernel_supports(int k) { return k >= 1 && k <= 64; }
+
+void Engine::fix_ties(const SolveArgs &sa, tknnSolveInfo *info, hipStream_t s) {
+  const int64_t n = bvh_.size();
+  TeamArgs a;
+  std::memset(&a, 0, sizeof a);
+  a.bvh = bvh_.view();
+  a.halo = halo_view();
+  a.wide[0] = bvh_.wide_view();
+  if (halo_n_ > 0) a.wide[1] = halo_.wide_view();
+  a.start_radius = sa.start_radius;
+  a.k = sa.k;
+  a.out_idx = sa.d_idx;
+  a.out_dist = sa.d_dist;
+  a.out_fb = sa.d_fb;
+  a.tie = tie_;
+  a.tie_list = tie_list_;
+  a.counters = counters_;
+  hipDeviceProp_t prop;
+  OWLMI_HIP(hipGetDeviceProperties(&prop, device_));
+  using FixEntry = void (*)(TeamArgs, const int32_t *, int32_t);
+  static const FixEntry entries[2][3] = {{tie_fix_kernel<false, 1>, tie_fix_kernel<false, 2>, tie_fix_kernel<false, 4>},
+                                         {tie_fix_kernel<true, 1>, tie_fix_kernel<true, 2>, tie_fix_kernel<true, 4>}};
+  const FixEntry entry = entries[halo_n_ > 0 ? 1 : 0][sa.k <= 16 ? 0 : (sa.k <= 32 ? 1 : 2)];
+  auto launch = [&](int blocks, const int32_t *slots, int32_t nslots) {
+    void *kargs[] = {(void *)&a, (void *)&slots, (void *)&nslots};
+    OWLMI_HIP(hipLaunchKernel((const void *)entry, dim3(blocks), dim3(kTeamBlock), kargs, 0, s));
+  };
+  // First go: the kernels' own list, count read on the device -- no host round trip before the launch;
+  // the usual handful of rows (or none) costs one small launch behind the solve.
+  OWLMI_HIP(hipEventRecord(ev_a_, s));
+  launch(std::min(prop.multiProcessorCount * 4, kTieListCap / 4), tie_list_, -1);  // a team per listed row
+  OWLMI_HIP(hipEventRecord(ev_b_, s));
+  OWLMI_HIP(hipMemcpyAsync(h_counters_, counters_ + kTieCounter, 3 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+  OWLMI_HIP(hipStreamSynchronize(s));
+  float ms = 0;
+  OWLMI_HIP(hipEventElapsedTime(&ms, ev_a_, ev_b_));
+  const int64_t flagged = (int64_t)h_counters_[0];
+  if (flagged > kTieListCap) {
+    // more than the list holds (quantised coordinates, lattices): all flagged slots, compacted from tie_
+    // (rows redone twice come out the same: the gate is the row's k-th distance, which no order changes)
+    if (n > slot_list_cap_) {
+      if (slot_list_) (void)hipFree(slot_list_);
+      slot_list_ = nullptr;
+      OWLMI_HIP(hipMalloc((void **)&slot_list_, ((size_t)n + 1) * sizeof(int32_t)));
+      slot_list_cap_ = n;
+    }
+    int32_t *d_count = slot_list_ + n;
+    hipcub::CountingInputIterator<int32_t> iota(0);
+    hipcub::TransformInputIterator<bool, HasTie, const uint8_t *> flags(tie_, HasTie{});
+    size_t tmp_bytes = 0;
+    OWLMI_HIP(hipcub::DeviceSelect::Flagged(nullptr, tmp_bytes, iota, flags, slot_list_, d_count, (int)n, s));
+    if (tmp_bytes > wave_ws_bytes_) {
+      if (wave_ws_) (void)hipFree(wave_ws_);
+      wave_ws_ = nullptr;
+      OWLMI_HIP(hipMalloc(&wave_ws_, tmp_bytes));
+      wave_ws_bytes_ = tmp_bytes;
+    }
+    OWLMI_HIP(hipcub::DeviceSelect::Flagged(wave_ws_, tmp_bytes, iota, flags, slot_list_, d_count, (int)n, s));
+    OWLMI_HIP(hipMemsetAsync(counters_ + kTieCounter + 1, 0, 2 * sizeof(unsigned long long), s));
+    OWLMI_HIP(hipEventRecord(ev_a_, s));
+    launch((int)std::min<int64_t>((flagged + 3) / 4, (int64_t)prop.multiProcessorCount * 8), slot_list_, (int32_t)flagged);
+    OWLMI_HIP(hipEventRecord(ev_b_, s));
+    OWLMI_HIP(hipMemcpyAsync(h_counters_, counters_ + kTieCounter, 3 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+    OWLMI_HIP(hipStreamSynchronize(s));
+    float again = 0;
+    OWLMI_HIP(hipEventElapsedTime(&again, ev_a_, ev_b_));
+    ms += again;
+  }
+  if (flagged && getenv("TKNN_VERBOSE")) fprintf(stderr, "[ties] %lld rows redone in the reference's tie order: %.3f ms, %llu left\n", (long long)flagged, ms, h_counters_[2]);
+  if (info) {
+    info->tie_rows = flagged;
+    info->tie_rows_left = (int64_t)h_counters_[2];
+    info->tie_ms = ms;
+    info->solve_ms += ms;
+  }
+}
+
 
 // How many radius levels the first gather of every packet should serve: with the average density
 // of the scene, the first level at which a box is expected to hold about k/2 other points.  Only
@@ -1154,6 +1506,8 @@ bool Engine::solve_team(const SolveArgs &sa, tknnSolveInfo *info, hipStream_t s)
   a.out_fb = sa.d_fb;
   a.out_level = sa.d_levels;
   a.done = done_;
+  a.tie = tie_;
+  a.tie_list = tie_list_;
   a.isect_sorted = isect_sorted_;
   a.next_level = next_level_;
   a.counters = counters_;
@@ -1216,9 +1570,13 @@ bool Engine::solve_team(const SolveArgs &sa, tknnSolveInfo *info, hipStream_t s)
     if (info) *info = mine;
     return true;
   }
-  const void *entry = with_halo ? (wide_list ? (const void *)team_kernel<true, 2> : (const void *)team_kernel<true, 1>)
-                                : (wide_list ? (const void *)team_kernel<false, 2> : (const void *)team_kernel<false, 1>);
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, entry, kTeamBlock, lds) != hipSuccess) per_cu = 2;
+  const bool full_list = sa.k == (wide_list ? 32 : 16);  // no spare list entry to see a tie with the row's last in
+  using TeamEntry = void (*)(TeamArgs);
+  static const TeamEntry entries[2][2][2] = {
+      {{team_kernel<false, 1, false>, team_kernel<false, 1, true>}, {team_kernel<false, 2, false>, team_kernel<false, 2, true>}},
+      {{team_kernel<true, 1, false>, team_kernel<true, 1, true>}, {team_kernel<true, 2, false>, team_kernel<true, 2, true>}}};
+  const TeamEntry entry = entries[with_halo ? 1 : 0][wide_list ? 1 : 0][full_list ? 1 : 0];
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)entry, kTeamBlock, lds) != hipSuccess) per_cu = 2;
   per_cu = std::max(1, per_cu);
   const int64_t want = (a.ngroups + kTeamBlock / 64 - 1) / (kTeamBlock / 64);
   const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>(want, (int64_t)prop.multiProcessorCount * per_cu));
@@ -1228,14 +1586,10 @@ bool Engine::solve_team(const SolveArgs &sa, tknnSolveInfo *info, hipStream_t s)
   OWLMI_HIP(hipMemsetAsync(done_, 1, (size_t)n, s));
   if (sa.d_levels) OWLMI_HIP(hipMemsetAsync(sa.d_levels, 0xff, (size_t)n * sizeof(int32_t), s));
   OWLMI_HIP(hipEventRecord(ev_a_, s));
-  if (with_halo && wide_list)
-    hipLaunchKernelGGL((team_kernel<true, 2>), dim3(blocks), dim3(kTeamBlock), lds, s, a);
-  else if (with_halo)
-    hipLaunchKernelGGL((team_kernel<true, 1>), dim3(blocks), dim3(kTeamBlock), lds, s, a);
-  else if (wide_list)
-    hipLaunchKernelGGL((team_kernel<false, 2>), dim3(blocks), dim3(kTeamBlock), lds, s, a);
-  else
-    hipLaunchKernelGGL((team_kernel<false, 1>), dim3(blocks), dim3(kTeamBlock), lds, s, a);
+  {
+    void *kargs[] = {(void *)&a};
+    OWLMI_HIP(hipLaunchKernel((const void *)entry, dim3(blocks), dim3(kTeamBlock), kargs, lds, s));
+  }
   OWLMI_HIP(hipGetLastError());
   OWLMI_HIP(hipEventRecord(ev_b_, s));
   OWLMI_HIP(hipMemcpyAsync(h_counters_, counters_, 10 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));

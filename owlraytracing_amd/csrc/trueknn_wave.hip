@@ -44,6 +44,8 @@ struct WaveArgs {
   LbvhView halo;      // second point set searched by every query (n == 0: none)
   int32_t *out_level; // n, caller order (may be null)
   const uint8_t *skip_done;  // per sorted slot, may be null: queries another kernel has finished already
+  uint8_t *tie;              // per sorted slot: 1 + level for rows finished with exact-distance ties (knn_flag_tie)
+  int32_t *tie_list;
   int allow_unfinished;
   float start_radius;
   int k;
@@ -319,6 +321,7 @@ __global__ void __launch_bounds__(kWaveBlock) wave_packet_kernel(WaveArgs a) {
         finished = st.others >= (uint32_t)a.k;
         if (finished) {
           emit_row<K>(a, bvh.prim_id[slot], level, st.list, isect);
+          if (st.list.has_ties(a.k)) knn_flag_tie(a.tie, a.tie_list, a.counters, slot, level);  // redone by tie_fix_kernel in the reference's tie order
           my_isect_sum += (unsigned long long)isect;
         }
       }
@@ -389,6 +392,8 @@ void Engine::solve_wave(const SolveArgs &sa, tknnSolveInfo *info, hipStream_t s,
   a.bvh = bvh_.view();
   a.halo = halo_view();
   a.out_level = sa.d_levels;
+  a.tie = tie_;
+  a.tie_list = tie_list_;
   a.skip_done = only_unfinished ? done_ : nullptr;  // the team kernel's stragglers, solved from level 0
   a.allow_unfinished = sa.allow_unfinished ? 1 : 0;
   a.start_radius = sa.start_radius;

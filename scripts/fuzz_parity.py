@@ -14,7 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import oracle  # noqa: E402
-from conftest import assert_rows_equal_modulo_cross_round_ties  # noqa: E402
+from conftest import assert_rows_equal  # noqa: E402
 from owlraytracing_amd import _lib, datasets  # noqa: E402
 from owlraytracing_amd.trueknn import TrueKNN  # noqa: E402
 
@@ -68,7 +68,7 @@ def main():
             assert r["info"]["rounds"] == ref["rounds"], tag
             assert np.array_equal(r["intersections"].cpu().numpy(), ref["intersections"]), tag
             try:
-                assert_rows_equal_modulo_cross_round_ties(r["idx"].cpu().numpy(), r["dist"].cpu().numpy(), ref["idx"], ref["dist"])
+                assert_rows_equal(r["idx"].cpu().numpy(), r["dist"].cpu().numpy(), ref["idx"], ref["dist"])
             except AssertionError as e:
                 raise AssertionError(tag + ": " + str(e))
         halo_note = ""
@@ -87,7 +87,7 @@ def main():
                     tag = "halo %s n=%d own=%d k=%d r0=%g kernel=%d" % (name, n, len(own), k, r0, kern)
                     assert np.array_equal(r["intersections"].cpu().numpy(), sub["intersections"][own]), tag
                     try:
-                        assert_rows_equal_modulo_cross_round_ties(r["idx"].cpu().numpy(), r["dist"].cpu().numpy(), sub["idx"][own], sub["dist"][own])
+                        assert_rows_equal(r["idx"].cpu().numpy(), r["dist"].cpu().numpy(), sub["idx"][own], sub["dist"][own])
                     except AssertionError as e:
                         raise AssertionError(tag + ": " + str(e))
                 eng.set_halo(None, None)

@@ -5,7 +5,7 @@ import pytest
 import oracle
 from owlraytracing_amd import _lib, datasets
 
-from conftest import assert_rows_equal_modulo_cross_round_ties, assert_rows_match
+from conftest import assert_rows_equal, assert_rows_match
 
 pytestmark = pytest.mark.gpu
 
@@ -37,21 +37,17 @@ def test_golden_vectors(golden, kernel):
     assert r["info"]["kernel_used"] in ((kernel, _lib.KERNEL_WAVE) if kernel == _lib.KERNEL_TEAM else (kernel,))
     assert r["info"]["rounds"] == int(golden["rounds"])
     assert np.float32(r["info"]["final_radius"]) == golden["final_radius"]
-    # the engines order exact distance ties by index, the replay by (round first seen, index)
-    replay_ties = not golden["name"].startswith("crossroundties")
-    if replay_ties:
-        assert_rows_match(r["idx"].cpu().numpy(), r["dist"].cpu().numpy(), r["intersections"].cpu().numpy(), golden)
-    else:
-        assert assert_rows_equal_modulo_cross_round_ties(r["idx"].cpu().numpy(), r["dist"].cpu().numpy(), golden["idx"], golden["dist"]) > 0
-        assert np.array_equal(r["intersections"].cpu().numpy(), golden["intersections"])
+    # (crossroundties_*: exact distance ties between candidates of different rounds, which the replay --
+    # and the engines' tie pass -- order by the round first seen, then by index)
+    assert_rows_match(r["idx"].cpu().numpy(), r["dist"].cpu().numpy(), r["intersections"].cpu().numpy(), golden)
+    if golden["name"].startswith("crossroundties"):
+        assert r["info"]["tie_rows"] > 0 and r["info"]["tie_rows_left"] == 0
     assert r["info"]["total_intersections"] == int(golden["intersections"].sum())
     # frameBuffer image = what the reference leaves behind (GeomTypes.h:22-28 records)
     ref = oracle.trueknn(golden["xyz"], k, float(golden["start_radius"]))
     fb = _fb_view(r["fb"], len(golden["xyz"]), k)
     want = ref["fb"].reshape(len(golden["xyz"]), k)
     for field in ("ind", "dist", "numNeighbors", "intersections"):
-        if field == "ind" and not replay_ties:
-            continue
         assert np.array_equal(fb[field], want[field]), field
     eng.close()
 
@@ -68,8 +64,8 @@ def test_against_oracle_uniform(kernel, n, k, seed):
     eng.build(xyz)
     r = eng.solve(k, r0, kernel=kernel)
     assert r["info"]["rounds"] == ref["rounds"]
-    tied = assert_rows_equal_modulo_cross_round_ties(r["idx"].cpu().numpy(), r["dist"].cpu().numpy(), ref["idx"], ref["dist"])
-    assert tied <= 2  # exact fp32 distance ties between candidates of different rounds: a handful per million rows
+    assert_rows_equal(r["idx"].cpu().numpy(), r["dist"].cpu().numpy(), ref["idx"], ref["dist"])
+    assert r["info"]["tie_rows_left"] == 0
     assert np.array_equal(r["intersections"].cpu().numpy(), ref["intersections"])
     eng.close()
 
@@ -168,24 +164,65 @@ def test_team_kernel_tails_agree_when_everything_is_handed_over(monkeypatch, tai
 
 @pytest.mark.parametrize("kernel", KERNELS, ids=KERNEL_IDS)
 def test_exact_distance_ties_across_rounds(kernel):
-    """The one place where the engines are not the replay: candidates at bit-identical distances that
-    entered the reference's persistent list in different rounds (oracle/trueknn_oracle.c, decision 2).
-    The engines order every exact tie by index; everything else -- distances, intersection counts,
-    every row without such a tie -- must still be the replay's."""
+    """Candidates at bit-identical distances that entered the reference's persistent list in different
+    rounds keep that order whatever their indices (oracle/trueknn_oracle.c, decision 2).  The kernels
+    list by (dist, index) and flag such rows; tie_fix_kernel redoes them with the round as the second
+    key word.  The set is built so that index order and round order disagree."""
     xyz = datasets.cross_round_ties()
     ref = oracle.trueknn(xyz, 2, 1.0)
     assert ref["rounds"] >= 2
+    # the construction does produce rows where plain (dist, index) order is not the replay's
+    plain = np.lexsort((ref["idx"], ref["dist"]), axis=1)
+    assert (plain != np.arange(2)[None, :]).any()
     eng = _engine()
     eng.build(xyz)
-    r = eng.solve(2, 1.0, kernel=kernel)
-    idx, dist = r["idx"].cpu().numpy(), r["dist"].cpu().numpy()
+    r = eng.solve(2, 1.0, kernel=kernel, want_fb=True)
     assert np.array_equal(r["intersections"].cpu().numpy(), ref["intersections"])
-    tied = assert_rows_equal_modulo_cross_round_ties(idx, dist, ref["idx"], ref["dist"])
-    assert tied > 0  # the construction does produce rows that depend on it
-    # and the engines' own rule: ties by index
-    same = dist[:, 1:] == dist[:, :-1]
-    assert np.all(idx[:, 1:][same] > idx[:, :-1][same])
+    assert_rows_equal(r["idx"].cpu().numpy(), r["dist"].cpu().numpy(), ref["idx"], ref["dist"])
+    assert r["info"]["tie_rows"] > 0 and r["info"]["tie_rows_left"] == 0
+    fb = _fb_view(r["fb"], len(xyz), 2)
+    assert np.array_equal(fb["ind"], ref["fb"].reshape(len(xyz), 2)["ind"])
+    # without distances to gate with, the pass still lands on the same rows
+    r2 = eng.solve(2, 1.0, kernel=kernel, out={"dist": None})
+    assert np.array_equal(r2["idx"].cpu().numpy(), ref["idx"])
     eng.close()
+
+
+def _lattice(m, dims, seed, drop=0.2):
+    g = np.arange(m, dtype=np.float32) / np.float32(32)
+    if dims == 3:
+        xyz = np.stack(np.meshgrid(g, g, g, indexing="ij"), -1).reshape(-1, 3)
+    else:
+        xy = np.stack(np.meshgrid(g, g, indexing="ij"), -1).reshape(-1, 2)
+        xyz = np.concatenate([xy, np.zeros((len(xy), 1), np.float32)], 1)
+    rng = np.random.default_rng(seed)
+    xyz = xyz[rng.random(len(xyz)) > drop]
+    return np.ascontiguousarray(xyz[rng.permutation(len(xyz))])
+
+
+@pytest.mark.parametrize("kernel", KERNELS, ids=KERNEL_IDS)
+@pytest.mark.parametrize("tail", [None, "walk", "lane"])
+@pytest.mark.parametrize("k", [1, 5, 16, 17, 32, 33, 64])
+def test_tie_heavy_sets_equal_the_replay(kernel, tail, k, monkeypatch):
+    """Lattices with holes and coarsely quantised coordinates: almost every row has bit-identical
+    distances inside it or at its end, many of them between candidates of different rounds.  k = 16,
+    32, 64 fill a team's list to the last entry (the tie with the best candidate left out is then
+    seen by what leaves the list, not by a spare entry)."""
+    if tail and kernel != _lib.KERNEL_TEAM:
+        pytest.skip("tails belong to the team kernel")
+    if tail:
+        monkeypatch.setenv("TKNN_TEAM_TAIL", tail)
+    sets = [(_lattice(14, 3, k), 0.02), (_lattice(50, 2, k), 0.011),
+            ((np.round(datasets.uniform3d(20_000, seed=k) * 64) / 64).astype(np.float32), 0.01)]
+    for xyz, r0 in sets:
+        ref = oracle.trueknn(xyz, k, r0)
+        eng = _engine()
+        eng.build(xyz)
+        r = eng.solve(k, r0, kernel=kernel)
+        assert np.array_equal(r["intersections"].cpu().numpy(), ref["intersections"])
+        assert_rows_equal(r["idx"].cpu().numpy(), r["dist"].cpu().numpy(), ref["idx"], ref["dist"])
+        assert r["info"]["tie_rows"] > 0 and r["info"]["tie_rows_left"] == 0
+        eng.close()
 
 
 def test_candidate_thresholds_equal_the_literal_box_test():
