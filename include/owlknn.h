@@ -19,8 +19,9 @@
  *
  * The same library also exports the reference's own owl* entry points (include/owl/owl_host.h),
  * which run user raygen / intersect / bounds programs over the same LBVH; the tknn* calls are the
- * fused form of the loop above and give bit-identical rows (modulo the order of exact ties, which
- * the reference leaves to traversal order; tknn* always orders ties by index).
+ * fused form of the loop above and give bit-identical rows (modulo the order of exact ties inside
+ * one round, which the reference leaves to traversal order; tknn* orders ties by the round in which a
+ * candidate was first seen -- the reference's lists persist over rounds -- and then by index).
  *
  * Conventions: plain C, pointers and sizes only.  `d_` pointers are device (HBM) addresses valid
  * on the engine's device.  `stream` is a hipStream_t passed as void* (NULL = default stream).

@@ -37,9 +37,9 @@
  *       ties depend on it.  One exception, because the lists persist over rounds
  *       (deviceCode.cu:77-85 skips what is listed already): of two candidates at bit-identical fp32
  *       distances the one that entered in an EARLIER round stays ahead whatever its index.  This
- *       replay reproduces that; the HIP engines order all exact ties by index (a handful of rows
- *       per million; tests/conftest.py::assert_rows_equal_modulo_cross_round_ties checks that
- *       nothing else differs).
+ *       replay reproduces that, and so do the HIP engines (their kernels list by (dist, index) and
+ *       flag the rows where the round matters; a second pass redoes those with the full key --
+ *       tests/conftest.py::assert_rows_equal demands index-for-index equality).
  *   (3) distance arithmetic: d = sqrtf((dx*dx + dy*dy) + dz*dz), every operation rounded to fp32
  *       on its own, i.e. deviceCode.cu:110-113 exactly as written, and a correctly rounded IEEE
  *       sqrt.  The reference's Release build lets nvcc contract the sum into fmas of its choosing
