@@ -80,6 +80,33 @@ def test_visit_order_changes_only_ties():
             assert set(a["idx"][q]) != set(b["idx"][q]) or len(np.unique(a["dist"][q])) < 6
 
 
+def test_replay_and_numpy_restatement_agree_on_tie_heavy_sets():
+    """Lattices with holes and coarsely quantised coordinates: most rows hold bit-identical distances,
+    many between candidates first seen in different rounds.  The call-by-call replay (persistent
+    lists, deviceCode.cu:77-85,116-134) and the independent numpy restatement (sort by distance,
+    first round, index) must give the same rows index for index -- the rule the engines' tie pass
+    is then held to (tests/test_trueknn_gpu.py::test_tie_heavy_sets_equal_the_replay)."""
+    from oracle.trueknn_numpy import trueknn_numpy
+    g = np.arange(9, dtype=np.float32) / np.float32(32)
+    lattice = np.stack(np.meshgrid(g, g, g, indexing="ij"), -1).reshape(-1, 3)
+    rng = np.random.default_rng(3)
+    lattice = lattice[rng.random(len(lattice)) > 0.2]
+    lattice = np.ascontiguousarray(lattice[rng.permutation(len(lattice))])
+    quant = (np.round(datasets.uniform3d(1500, seed=8) * 32) / 32).astype(np.float32)
+    crossed = 0
+    for xyz, k, r0 in ((lattice, 5, 0.02), (lattice, 16, 0.02), (quant, 3, 0.02), (quant, 10, 0.015), (datasets.cross_round_ties(), 2, 1.0)):
+        a = oracle.trueknn(xyz, k, r0)
+        b = trueknn_numpy(xyz, k, r0)
+        assert a["rounds"] == b["rounds"] >= 2
+        assert np.array_equal(a["dist"].view(np.int32), b["dist"].view(np.int32))
+        assert np.array_equal(a["intersections"], b["intersections"])
+        assert np.array_equal(a["idx"], b["idx"])
+        # rows where the plain (dist, index) order is NOT the answer: the round word matters there
+        tie = a["dist"][:, 1:] == a["dist"][:, :-1]
+        crossed += int(np.any(tie & (a["idx"][:, 1:] < a["idx"][:, :-1]), axis=1).sum())
+    assert crossed > 0
+
+
 def test_query_subset_equals_full_rows():
     xyz = datasets.uniform3d(5000, seed=4)
     full = oracle.trueknn(xyz, 5, datasets.start_radius(5000, 5))
