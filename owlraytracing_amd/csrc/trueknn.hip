@@ -493,7 +493,7 @@ void Engine::solve(const SolveArgs &sa, int kernel, tknnSolveInfo *info, hipStre
   if (kernel == TKNN_KERNEL_TEAM && !team_kernel_supports(sa.k))
     throw ArgError{TKNN_E_UNSUPPORTED, "the team kernels hold up to four neighbours per lane of a 16-lane team: k <= 64"};
   if (kernel == TKNN_KERNEL_AUTO) {
-    // team kernels for every k the engine takes (<= 64; above 32 the team walk alone): they hand what it cannot hold (outliers, dense duplicates, start radii
+    // team kernels for every k the engine takes (<= 64): they hand what it cannot hold (outliers, dense duplicates, start radii
     // far too large) to lane rounds or the wave kernel by itself; measured fastest from r0 = 2e-5 to
     // r0 = 0.04 on 10 M uniform points and on the clustered sets of profiles/
     if (team_kernel_supports(sa.k))

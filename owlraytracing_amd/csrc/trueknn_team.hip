@@ -1,4 +1,4 @@
-// trueknn_team.hip -- the team TrueKNN kernel (TKNN_KERNEL_TEAM), k <= 32 (k > 16: two list registers per lane).
+// trueknn_team.hip -- the team TrueKNN kernel (TKNN_KERNEL_TEAM), k <= 64 (k > 16: two list registers per lane, k > 32: four).
 //
 // The wave-packet kernel (trueknn_wave.hip) broadcasts every candidate of a 64-query packet to all
 // 64 lanes; on MI355X it is VALU-issue-bound with ~2.5 % useful lanes (profiles/r01_wave_v2_*),
@@ -230,7 +230,7 @@ __device__ __forceinline__ bool tie_may_straddle(float d, float r0, float r_last
 // One pass of the four teams over a compact list of queries.  SELECT = false: count candidates
 // (deviceCode.cu:74,103).  SELECT = true: also keep the k best (dist,index) keys, lane j of the
 // team holding the j-th, and write the row if the query turns out finished (>= k others).
-// NREG: list registers per lane -- the team's sorted list holds 16 * NREG keys (k <= 16: 1, k <= 32: 2)
+// NREG: list registers per lane -- the team's sorted list holds 16 * NREG keys (k <= 16: 1, k <= 32: 2, k <= 64: 4)
 template <bool SELECT, bool HALO, int NREG, bool FULL>
 __device__ __forceinline__ void team_pass(const TeamArgs &a, const TeamLds &L, int n_list, float r_inner, int m,
                                           const LbvhPoint *own_pts, const LbvhPoint *halo_pts, int lane) {
@@ -296,8 +296,12 @@ __device__ __forceinline__ void team_pass(const TeamArgs &a, const TeamLds &L, i
       return j == 0 ? e0 : (j == 1 ? e1 : (j == 2 ? e2 : (j == 3 ? e3 : (j == 4 ? e4 : e5))));
     };
     uint32_t cnt = 0;
-    uint32_t best_d = 0x7f7fffffu, best_i = 0u;  // KNN_EMPTY_KEY = {FLT_MAX, 0}
-    uint32_t best_d1 = 0x7f7fffffu, best_i1 = 0u;  // entries 16..31 (NREG == 2)
+    uint32_t bd[NREG], bi[NREG];  // register j of lane t holds list entry 16 j + t (indices are compile-time: stays in VGPRs)
+#pragma unroll
+    for (int j = 0; j < NREG; j++) {
+      bd[j] = 0x7f7fffffu;  // KNN_EMPTY_KEY = {FLT_MAX, 0}
+      bi[j] = 0u;
+    }
     // k == list size: the smallest distance (bits) among the keys that found no room, tracked in the lane
     // of the last entry -- equal to the k-th distance iff a candidate tied with the row's last stayed out
     // (FULL is a template parameter: as a run-time flag the three instructions it adds to an insert
@@ -306,7 +310,9 @@ __device__ __forceinline__ void team_pass(const TeamArgs &a, const TeamLds &L, i
     uint32_t left_out = 0xffffffffu;
     // the k-th best of my team, whose distance gates further candidates
     auto kth_dist = [&]() -> float {
-      const uint32_t reg = (NREG > 1 && a.k > 16) ? best_d1 : best_d;
+      uint32_t reg = bd[0];
+#pragma unroll
+      for (int j = 1; j < NREG; j++) reg = ((a.k - 1) >> 4) == j ? bd[j] : reg;
       return __uint_as_float(t_lane_read(reg, (team << 4) + ((a.k - 1) & 15)));
     };
     float tau2 = INFINITY;
@@ -343,32 +349,34 @@ __device__ __forceinline__ void team_pass(const TeamArgs &a, const TeamLds &L, i
             const int src = (team << 4) + (has ? __ffs((int)pending_mine) - 1 : 0);
             const uint32_t cd = t_lane_read(key_d, src), ci = t_lane_read(key_i, src);
             const uint64_t c = ((uint64_t)cd << 32) | ci;
-            const uint64_t cur = ((uint64_t)best_d << 32) | best_i;
-            const uint32_t pd = t_team_shr1(best_d), pi = t_team_shr1(best_i);
-            const uint64_t prev = ((uint64_t)pd << 32) | pi;  // lane 0: key 0, never greater than c
-            // a team with nothing to insert in this step keeps its list (has is uniform per team)
-            const bool take_prev = has & (tl != 0) & (c < prev);
-            const bool take_c = has & (c < cur);
-            const uint64_t nw = take_prev ? prev : (take_c ? c : cur);
-            if (NREG == 1 && full) left_out = has ? min(left_out, take_c ? best_d : cd) : left_out;
-            if (NREG > 1) {
-              // second register: its lane 0 follows lane 15 of the first (row_ror:1 brings it round)
-              const uint64_t cur1 = ((uint64_t)best_d1 << 32) | best_i1;
-              // (combined with a lane mask, not with a select: hipcc 7.2 miscompiles a select between two
-              // DPP moves -- lane 0 of the row reads 0; checked with a 20-line kernel on gfx950)
-              const uint32_t lane0 = tl == 0 ? 0xffffffffu : 0u;
-              const uint32_t qd = t_team_shr1(best_d1) | (t_dpp<0x121>(best_d) & lane0);
-              const uint32_t qi = t_team_shr1(best_i1) | (t_dpp<0x121>(best_i) & lane0);
-              const uint64_t prev1 = ((uint64_t)qd << 32) | qi;
-              const bool take_prev1 = has & (c < prev1);
-              const bool take_c1 = has & (c < cur1);
-              const uint64_t nw1 = take_prev1 ? prev1 : (take_c1 ? c : cur1);
-              if (full) left_out = has ? min(left_out, take_c1 ? best_d1 : cd) : left_out;
-              best_d1 = (uint32_t)(nw1 >> 32);
-              best_i1 = (uint32_t)nw1;
+            // every register shifts like one 16 * NREG long list: lane 0 of register j follows lane 15 of
+            // register j - 1 (row_ror:1 brings it round; combined with a lane mask, not with a select:
+            // hipcc 7.2 miscompiles a select between two DPP moves -- lane 0 of the row reads 0; checked
+            // with a 20-line kernel on gfx950).  A team with nothing to insert in this step keeps its
+            // list (has is uniform per team).
+            const uint32_t lane0 = tl == 0 ? 0xffffffffu : 0u;
+            uint32_t nd_[NREG], ni_[NREG];
+#pragma unroll
+            for (int j = 0; j < NREG; j++) {
+              const uint64_t cur = ((uint64_t)bd[j] << 32) | bi[j];
+              uint32_t pd = t_team_shr1(bd[j]), pi = t_team_shr1(bi[j]);
+              if (j > 0) {
+                pd |= t_dpp<0x121>(bd[j - 1]) & lane0;
+                pi |= t_dpp<0x121>(bi[j - 1]) & lane0;
+              }
+              const uint64_t prev = ((uint64_t)pd << 32) | pi;  // entry 0: key 0, never greater than c
+              const bool take_prev = has & ((j > 0) | (tl != 0)) & (c < prev);
+              const bool take_c = has & (c < cur);
+              const uint64_t nw = take_prev ? prev : (take_c ? c : cur);
+              if (full && j == NREG - 1) left_out = has ? min(left_out, take_c ? bd[j] : cd) : left_out;
+              nd_[j] = (uint32_t)(nw >> 32);
+              ni_[j] = (uint32_t)nw;
             }
-            best_d = (uint32_t)(nw >> 32);
-            best_i = (uint32_t)nw;
+#pragma unroll
+            for (int j = 0; j < NREG; j++) {
+              bd[j] = nd_[j];
+              bi[j] = ni_[j];
+            }
             pm &= ~__ballot(lane == src);  // the four lanes just served (a team without one names a lane that was not pending)
           } while (pm);
           tau2 = knn_gate_from_worst(kth_dist());
@@ -399,25 +407,25 @@ __device__ __forceinline__ void team_pass(const TeamArgs &a, const TeamLds &L, i
       cnt = t_count(cnt, __ballot(in));
       bool cand = in && (p.id != t_qid);
       if (TKNN_DIAG_BUILD && (a.diag & 1)) cand = false;
-      best_d = cand ? __float_as_uint(knn_sqrt(t_dist2(dx, dy, dz))) : 0x7f7fffffu;
-      best_i = cand ? (uint32_t)p.id : 0u;
+      bd[0] = cand ? __float_as_uint(knn_sqrt(t_dist2(dx, dy, dz))) : 0x7f7fffffu;
+      bi[0] = cand ? (uint32_t)p.id : 0u;
       const bool up1 = (tl & 1) != 0, up2 = (tl & 2) != 0, up4 = (tl & 4) != 0, up8 = (tl & 8) != 0;
       auto exchange = [&](uint32_t pd, uint32_t pi, bool upper) {
-        const uint64_t mine = ((uint64_t)best_d << 32) | best_i, other = ((uint64_t)pd << 32) | pi;
+        const uint64_t mine = ((uint64_t)bd[0] << 32) | bi[0], other = ((uint64_t)pd << 32) | pi;
         const bool take = (other < mine) != upper;  // lower lane: the smaller key; upper lane: the larger (equal: either)
-        best_d = take ? pd : best_d;
-        best_i = take ? pi : best_i;
+        bd[0] = take ? pd : bd[0];
+        bi[0] = take ? pi : bi[0];
       };
-      exchange(t_dpp<0xb1>(best_d), t_dpp<0xb1>(best_i), up1);    // pairs
-      exchange(t_dpp<0x1b>(best_d), t_dpp<0x1b>(best_i), up2);    // mirror within 4
-      exchange(t_dpp<0xb1>(best_d), t_dpp<0xb1>(best_i), up1);
-      exchange(t_dpp<0x141>(best_d), t_dpp<0x141>(best_i), up4);  // mirror within 8 (row_half_mirror)
-      exchange(t_dpp<0x4e>(best_d), t_dpp<0x4e>(best_i), up2);    // xor 2
-      exchange(t_dpp<0xb1>(best_d), t_dpp<0xb1>(best_i), up1);
-      exchange(t_dpp<0x140>(best_d), t_dpp<0x140>(best_i), up8);  // mirror within 16 (row_mirror)
-      exchange(t_xor4(best_d), t_xor4(best_i), up4);
-      exchange(t_dpp<0x4e>(best_d), t_dpp<0x4e>(best_i), up2);
-      exchange(t_dpp<0xb1>(best_d), t_dpp<0xb1>(best_i), up1);
+      exchange(t_dpp<0xb1>(bd[0]), t_dpp<0xb1>(bi[0]), up1);    // pairs
+      exchange(t_dpp<0x1b>(bd[0]), t_dpp<0x1b>(bi[0]), up2);    // mirror within 4
+      exchange(t_dpp<0xb1>(bd[0]), t_dpp<0xb1>(bi[0]), up1);
+      exchange(t_dpp<0x141>(bd[0]), t_dpp<0x141>(bi[0]), up4);  // mirror within 8 (row_half_mirror)
+      exchange(t_dpp<0x4e>(bd[0]), t_dpp<0x4e>(bi[0]), up2);    // xor 2
+      exchange(t_dpp<0xb1>(bd[0]), t_dpp<0xb1>(bi[0]), up1);
+      exchange(t_dpp<0x140>(bd[0]), t_dpp<0x140>(bi[0]), up8);  // mirror within 16 (row_mirror)
+      exchange(t_xor4(bd[0]), t_xor4(bi[0]), up4);
+      exchange(t_dpp<0x4e>(bd[0]), t_dpp<0x4e>(bi[0]), up2);
+      exchange(t_dpp<0xb1>(bd[0]), t_dpp<0xb1>(bi[0]), up1);
       tau2 = knn_gate_from_worst(kth_dist());  // k > 16: the second register is still empty, the gate stays open
       first_sorted = true;
     }
@@ -445,21 +453,23 @@ __device__ __forceinline__ void team_pass(const TeamArgs &a, const TeamLds &L, i
     uint32_t tied = 0u;
     if (SELECT) {
       // entry j against entry j - 1, for j = 1..k (KList::has_ties is the per-lane form of this)
-      bool tie0 = (tl >= 1) & (tl <= a.k) & (best_d == t_team_shr1(best_d)), tie1 = false;
-      if (NREG > 1) {
-        const uint32_t lane0 = tl == 0 ? 0xffffffffu : 0u;
-        const uint32_t before = t_team_shr1(best_d1) | (t_dpp<0x121>(best_d) & lane0);
-        tie1 = (16 + tl <= a.k) & (best_d1 == before);
-        if (full) tie1 |= (tl == 15) & (left_out == best_d1);
-      } else if (full) {
-        tie0 |= (tl == 15) & (left_out == best_d);
+      bool tie[NREG];
+      bool any = false;
+#pragma unroll
+      for (int j = 0; j < NREG; j++) {
+        uint32_t before = t_team_shr1(bd[j]);
+        if (j > 0) before |= t_dpp<0x121>(bd[j - 1]) & (tl == 0 ? 0xffffffffu : 0u);
+        tie[j] = ((j > 0) | (tl >= 1)) & (16 * j + tl <= a.k) & (bd[j] == before);
+        if (full && j == NREG - 1) tie[j] |= (tl == 15) & (left_out == bd[j]);
+        any |= tie[j];
       }
-      if (__ballot(tie0 | tie1) != 0ull) {  // rare: does any of them span two rounds?
+      if (__ballot(any) != 0ull) {  // rare: does any of them span two rounds?
         const float qmax = fmaxf(fmaxf(fabsf(t_qx), fabsf(t_qy)), fabsf(t_qz));
-        tie0 = tie0 && tie_may_straddle(__uint_as_float(best_d), a.start_radius, t_r, qmax);
-        if (NREG > 1) tie1 = tie1 && tie_may_straddle(__uint_as_float(best_d1), a.start_radius, t_r, qmax);
+        any = false;
+#pragma unroll
+        for (int j = 0; j < NREG; j++) any |= tie[j] && tie_may_straddle(__uint_as_float(bd[j]), a.start_radius, t_r, qmax);
       }
-      tied = ((uint32_t)(__ballot(tie0 | tie1) >> (team * 16)) & 0xffffu) ? 1u : 0u;
+      tied = ((uint32_t)(__ballot(any) >> (team * 16)) & 0xffffu) ? 1u : 0u;
     }
     if (on && tl == 0) {
       // counts innermost level first; a one-level pass fills slot 0
@@ -481,10 +491,9 @@ __device__ __forceinline__ void team_pass(const TeamArgs &a, const TeamLds &L, i
         for (int reg = 0; reg < NREG; reg++) {
           const int j = tl + 16 * reg;  // my entry of this register
           if (j >= a.k) continue;
-          const uint32_t bd = reg == 0 ? best_d : best_d1, bi = reg == 0 ? best_i : best_i1;
           const int64_t o = (int64_t)out_row * a.k + j;
-          const int32_t prim = knn_key_prim(((uint64_t)bd << 32) | bi);
-          const float d = __uint_as_float(bd);
+          const int32_t prim = knn_key_prim(((uint64_t)bd[reg] << 32) | bi[reg]);
+          const float d = __uint_as_float(bd[reg]);
           if (a.out_idx) a.out_idx[o] = prim;
           if (a.out_dist) a.out_dist[o] = d;
           if (a.out_fb) {
@@ -747,18 +756,37 @@ __global__ void __launch_bounds__(kTeamBlock) __attribute__((amdgpu_waves_per_eu
         }
         t_wave_sync();  // the stack array is rewritten by the next tree / shared with the passes
       }
-      if (__ballot(my_nblk > kMaxPerQuery) != 0ull) too_big = true;  // a query needs more blocks than its list holds
-      if (too_big) {
-        // hand the packet's unfinished queries over to the lane kernel, from this level on
-        if (active) {
+      // The packet's block list or scan budget is exhausted, or a query needs more blocks than its own
+      // list holds: the packet's unfinished queries are handed over (team walk / lane rounds / wave
+      // kernel, see solve_team), from this level on.  With four list registers (k > 32: boxes of
+      // hundreds of candidates at the last level) only the queries whose own lists overflow go and
+      // the rest carry on -- 0.49 M instead of 2.3 M of 10 M uniform points at k = 50.  (For k <= 32
+      // that finer hand-over changed little on the clustered sets and cost 1 % on the benchmark: the
+      // loop no longer ends at this point, which moved the register allocation.)
+      if (NREG < 4) {
+        if (__ballot(my_nblk > kMaxPerQuery) != 0ull) too_big = true;
+        if (too_big) {
+          if (active) {
+            a.done[slot] = 0;
+            a.isect_sorted[slot] = isect;
+            a.next_level[slot] = level;
+            my_handed++;
+          }
+          wave_min_handover = min(wave_min_handover, level);
+          active = false;
+          break;
+        }
+      } else if (too_big || __ballot(my_nblk > kMaxPerQuery) != 0ull) {
+        const bool hand_over = active && (too_big || my_nblk > kMaxPerQuery);
+        if (hand_over) {
           a.done[slot] = 0;
           a.isect_sorted[slot] = isect;
           a.next_level[slot] = level;
           my_handed++;
+          active = false;
         }
         wave_min_handover = min(wave_min_handover, level);
-        active = false;
-        break;
+        if (__ballot(active) == 0ull) break;
       }
       if (TKNN_DIAG_BUILD && (a.diag & 32)) diag_listed += nb;
       const int my_packed = my_nblk | (my_own_pos << 8);  // read back by the teams
@@ -1517,9 +1545,11 @@ bool Engine::solve_team(const SolveArgs &sa, tknnSolveInfo *info, hipStream_t s)
   int per_cu = 2;
   const size_t lds = (size_t)kTeamBlock / 64 * kTeamLds;
   const bool with_halo = halo_n_ > 0;
-  const bool wide_list = sa.k > 16;  // two list registers per lane
-  if (sa.k > 32) {
-    // 33 <= k <= 64: the packet kernel's lists (96 blocks per query) would overflow at once; every
+  const int nreg = sa.k <= 16 ? 1 : (sa.k <= 32 ? 2 : 4);  // list registers per lane
+  const int nreg_at = nreg == 4 ? 2 : nreg - 1;           // index into the tables of instantiations
+  const char *walk_all = getenv("TKNN_TEAM_WALK_ALL");    // measurements only: k > 32 without the packet kernel
+  if (sa.k > 32 && walk_all && atoi(walk_all)) {
+    // (33 <= k <= 64 as it was before the packet kernel had four list registers per lane:) every
     // query goes through the team walk, four list registers per lane, from level 0
     OWLMI_HIP(hipMemsetAsync(counters_, 0, 32 * sizeof(unsigned long long), s));
     OWLMI_HIP(hipMemsetAsync(done_, 0, (size_t)n, s));
@@ -1570,12 +1600,14 @@ bool Engine::solve_team(const SolveArgs &sa, tknnSolveInfo *info, hipStream_t s)
     if (info) *info = mine;
     return true;
   }
-  const bool full_list = sa.k == (wide_list ? 32 : 16);  // no spare list entry to see a tie with the row's last in
+  const bool full_list = sa.k == 16 * nreg;  // no spare list entry to see a tie with the row's last in
   using TeamEntry = void (*)(TeamArgs);
-  static const TeamEntry entries[2][2][2] = {
-      {{team_kernel<false, 1, false>, team_kernel<false, 1, true>}, {team_kernel<false, 2, false>, team_kernel<false, 2, true>}},
-      {{team_kernel<true, 1, false>, team_kernel<true, 1, true>}, {team_kernel<true, 2, false>, team_kernel<true, 2, true>}}};
-  const TeamEntry entry = entries[with_halo ? 1 : 0][wide_list ? 1 : 0][full_list ? 1 : 0];
+  static const TeamEntry entries[2][3][2] = {
+      {{team_kernel<false, 1, false>, team_kernel<false, 1, true>}, {team_kernel<false, 2, false>, team_kernel<false, 2, true>},
+       {team_kernel<false, 4, false>, team_kernel<false, 4, true>}},
+      {{team_kernel<true, 1, false>, team_kernel<true, 1, true>}, {team_kernel<true, 2, false>, team_kernel<true, 2, true>},
+       {team_kernel<true, 4, false>, team_kernel<true, 4, true>}}};
+  const TeamEntry entry = entries[with_halo ? 1 : 0][nreg_at][full_list ? 1 : 0];
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)entry, kTeamBlock, lds) != hipSuccess) per_cu = 2;
   per_cu = std::max(1, per_cu);
   const int64_t want = (a.ngroups + kTeamBlock / 64 - 1) / (kTeamBlock / 64);
@@ -1631,7 +1663,7 @@ bool Engine::solve_team(const SolveArgs &sa, tknnSolveInfo *info, hipStream_t s)
     info->dominant_kernel_ms = ms;
     info->dominant_kernel_launches = 1;
     info->kernel_used = TKNN_KERNEL_TEAM;
-    info->list_capacity = 16;
+    info->list_capacity = 16 * nreg;
     info->unfinished = (int64_t)h_counters_[7];
   }
   const unsigned long long handed = h_counters_[8];
@@ -1645,7 +1677,9 @@ bool Engine::solve_team(const SolveArgs &sa, tknnSolveInfo *info, hipStream_t s)
     tknnSolveInfo tail;
     std::memset(&tail, 0, sizeof tail);
     const char *force = getenv("TKNN_TEAM_TAIL");  // "walk" / "lane" / "wave": tests and measurements only
-    const bool by_wave = wave_kernel_available() && (force ? !strcmp(force, "wave") : handed * 4ull >= (unsigned long long)n);
+    // (k > 32: the team walk beats the wave kernel's 64-entry register lists on any share, 10 M uniform
+    // points from level 0: 137 against 223 ms at k = 50)
+    const bool by_wave = wave_kernel_available() && (force ? !strcmp(force, "wave") : (handed * 4ull >= (unsigned long long)n && sa.k <= 32));
     const bool by_walk = !by_wave && !(force && !strcmp(force, "lane"));
     const int first_handover_level = (int)h_counters_[9];
     if (by_wave) {
@@ -1673,14 +1707,15 @@ bool Engine::solve_team(const SolveArgs &sa, tknnSolveInfo *info, hipStream_t s)
       OWLMI_HIP(hipMemsetAsync(counters_, 0, 16 * sizeof(unsigned long long), s));
       const int walk_blocks = (int)std::min<int64_t>((int64_t)(handed + 3) / 4, (int64_t)prop.multiProcessorCount * 16);
       OWLMI_HIP(hipEventRecord(ev_a_, s));
-      if (with_halo && wide_list)
-        hipLaunchKernelGGL((team_walk_kernel<true, 2>), dim3(walk_blocks), dim3(kTeamBlock), 0, s, a, slot_list_, (int32_t)handed);
-      else if (with_halo)
-        hipLaunchKernelGGL((team_walk_kernel<true, 1>), dim3(walk_blocks), dim3(kTeamBlock), 0, s, a, slot_list_, (int32_t)handed);
-      else if (wide_list)
-        hipLaunchKernelGGL((team_walk_kernel<false, 2>), dim3(walk_blocks), dim3(kTeamBlock), 0, s, a, slot_list_, (int32_t)handed);
-      else
-        hipLaunchKernelGGL((team_walk_kernel<false, 1>), dim3(walk_blocks), dim3(kTeamBlock), 0, s, a, slot_list_, (int32_t)handed);
+      {
+        using WalkEntry = void (*)(TeamArgs, const int32_t *, int32_t);
+        static const WalkEntry walks[2][3] = {{team_walk_kernel<false, 1>, team_walk_kernel<false, 2>, team_walk_kernel<false, 4>},
+                                              {team_walk_kernel<true, 1>, team_walk_kernel<true, 2>, team_walk_kernel<true, 4>}};
+        const int32_t *slots = slot_list_;
+        int32_t nslots = (int32_t)handed;
+        void *kargs[] = {(void *)&a, (void *)&slots, (void *)&nslots};
+        OWLMI_HIP(hipLaunchKernel((const void *)walks[with_halo ? 1 : 0][nreg_at], dim3(walk_blocks), dim3(kTeamBlock), kargs, 0, s));
+      }
       OWLMI_HIP(hipGetLastError());
       OWLMI_HIP(hipEventRecord(ev_b_, s));
       OWLMI_HIP(hipMemcpyAsync(h_counters_, counters_, 10 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
