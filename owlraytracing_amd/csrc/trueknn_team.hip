@@ -86,6 +86,7 @@ struct TeamArgs {
   int max_rounds;
   int allow_unfinished;
   int first_step;  // levels the first gather of every packet serves (density estimate, 1..kMaxStep)
+  float tie_span;  // sqrt(number of axes along which the points differ), rounded up: d <= tie_span * Chebyshev distance
   int diag;        // TKNN_DIAG_BUILD only: 1 skip inserts, 2 skip SELECT passes, 4 skip COUNT passes, 8 skip per-block query tests
   int32_t ngroups;
   int32_t *out_idx;
@@ -212,17 +213,18 @@ struct TeamLds {
 };
 
 // Can two candidates of one query at the same fp32 distance d have become candidates in DIFFERENT
-// rounds?  A candidate's Chebyshev distance t obeys d / sqrt(3) <= t <= d, and round l takes it iff
+// rounds?  A candidate's Chebyshev distance t obeys d / sqrt(3) <= t <= d (sqrt(2) for points in a
+// plane z = const, as the reference's 2-D inputs are: `span`), and round l takes it iff
 // t <= r_l (up to the rounding margin M of the box test, see team_kernel).  Going up the radii: if
 // d is safely below r_l, every candidate at distance d passes round l -- and none passed an earlier
 // round, or the loop would have stopped there; if not, but d / sqrt(3) can be below r_l, some may
 // pass and others not.  Exact duplicates (d = 0) and the other ties of quantised data mostly are of
 // the first kind and need no second look.  qmax = max |q|, r_last = the radius the query finished with.
-__device__ __forceinline__ bool tie_may_straddle(float d, float r0, float r_last, float qmax) {
+__device__ __forceinline__ bool tie_may_straddle(float d, float r0, float r_last, float qmax, float span) {
   for (float r = r0;; r = r * 2.0f) {
     const float mg = (qmax + 2.0f * r) * 4.76837158203125e-07f;  // 2^-21
     if (d <= (r - mg) * 0.99999f) return false;
-    if (d <= (r + mg) * 1.73206f) return true;  // t >= d / sqrt(3) > r + M otherwise: certainly not a candidate of round l
+    if (d <= (r + mg) * span) return true;  // t >= d / span > r + M otherwise: certainly not a candidate of round l
     if (!(r < r_last)) return true;  // (a listed candidate passes the last round's test: not reached)
   }
 }
@@ -467,7 +469,7 @@ __device__ __forceinline__ void team_pass(const TeamArgs &a, const TeamLds &L, i
         const float qmax = fmaxf(fmaxf(fabsf(t_qx), fabsf(t_qy)), fabsf(t_qz));
         any = false;
 #pragma unroll
-        for (int j = 0; j < NREG; j++) any |= tie[j] && tie_may_straddle(__uint_as_float(bd[j]), a.start_radius, t_r, qmax);
+        for (int j = 0; j < NREG; j++) any |= tie[j] && tie_may_straddle(__uint_as_float(bd[j]), a.start_radius, t_r, qmax, a.tie_span);
       }
       tied = ((uint32_t)(__ballot(any) >> (team * 16)) & 0xffffu) ? 1u : 0u;
     }
@@ -1160,7 +1162,7 @@ __global__ void __launch_bounds__(kTeamBlock) team_walk_kernel(TeamArgs a, const
             if (reg > 0) before |= t_dpp<0x121>(bd[reg - 1]) & (tl == 0 ? 0xffffffffu : 0u);
             bool t = ((reg > 0) | (tl >= 1)) & (16 * reg + tl <= a.k) & (bd[reg] == before);
             if (reg == NREG - 1 && full) t |= (tl == 15) & (left_out == bd[reg]);
-            tie |= t && tie_may_straddle(__uint_as_float(bd[reg]), a.start_radius, r, qmax);
+            tie |= t && tie_may_straddle(__uint_as_float(bd[reg]), a.start_radius, r, qmax, a.tie_span);
           }
           const bool tied = ((uint32_t)(__ballot(tie) >> (team * 16)) & 0xffffu) != 0u;
           if (tl == 0) {
@@ -1524,6 +1526,14 @@ bool Engine::solve_team(const SolveArgs &sa, tknnSolveInfo *info, hipStream_t s)
   a.max_rounds = sa.max_rounds;
   a.allow_unfinished = sa.allow_unfinished ? 1 : 0;
   a.first_step = first_step_estimate(sa);
+  {
+    // axes along which the built points differ at all (2-D inputs carry z = 0, hostCode.cpp:115-118);
+    // a halo tree may hold anything
+    int dims = 0;
+    for (int ax = 0; ax < 3; ax++) dims += scene_[3 + ax] > scene_[ax] ? 1 : 0;
+    if (halo_n_ > 0) dims = 3;
+    a.tie_span = dims >= 3 ? 1.73206f : (dims == 2 ? 1.41422f : 1.00001f);
+  }
   a.diag = 0;
   if (TKNN_DIAG_BUILD)
     if (const char *d = getenv("TKNN_TEAM_DIAG")) a.diag = atoi(d);
