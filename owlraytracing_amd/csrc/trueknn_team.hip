@@ -1028,11 +1028,18 @@ __global__ void __launch_bounds__(kTeamBlock) team_walk_kernel(TeamArgs a, const
           const WalkLevel wl = levels[tree][lvl];
           // the virtual root has the top level's few boxes as its children
           const int32_t nchild = lvl == wv.levels - 1 ? (first_child == 0 ? wl.count : 0) : wl.count;
+          LbvhBox bx4[4];  // the node's 64 child boxes, all four loads in flight at once
+#pragma unroll
+          for (int chunk = 0; chunk < 4; chunk++) {
+            const int32_t c = first_child + 16 * chunk + tl;
+            bx4[chunk] = LbvhBox{{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
+            if (work && c < nchild) bx4[chunk] = wl.boxes[c];
+          }
+#pragma unroll
           for (int chunk = 0; chunk < 4; chunk++) {
             const int32_t c = first_child + 16 * chunk + tl;
             const bool valid = work && c < nchild;
-            LbvhBox bx = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
-            if (valid) bx = wl.boxes[c];
+            const LbvhBox bx = bx4[chunk];
             const bool ov = valid & (bx.lo[0] <= q.x + rl) & (bx.hi[0] >= q.x - rl) & (bx.lo[1] <= q.y + rl) &
                             (bx.hi[1] >= q.y - rl) & (bx.lo[2] <= q.z + rl) & (bx.hi[2] >= q.z - rl);
             node_tests += valid ? 1u : 0u;
