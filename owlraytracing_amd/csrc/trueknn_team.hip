@@ -1087,6 +1087,7 @@ __global__ void __launch_bounds__(kTeamBlock) team_walk_kernel(TeamArgs a, const
                 part = t_count(part, in_m);
                 const float d2 = t_dist2(dx, dy, dz);
                 unsigned long long pm = in_m & __ballot(p.id != q.id) & __ballot(d2 <= tau2);
+                if (TKNN_DIAG_BUILD && (a.diag & 1)) pm = 0;
                 if (pm) {
                   const uint32_t key_d = __float_as_uint(knn_sqrt(d2));
                   const uint32_t key_i = (uint32_t)p.id;
