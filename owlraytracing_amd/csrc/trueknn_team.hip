@@ -1226,7 +1226,7 @@ __global__ void __launch_bounds__(kTeamBlock) team_walk_kernel(TeamArgs a, const
 // it passes (the test is monotone in r).  Only neighbours within the row's k-th distance can be
 // part of the answer, and that distance is already known (it does not depend on the order of ties):
 // the walk prunes with it from the start, so a row costs a few wide nodes and leaf blocks.
-constexpr int kFixStack = 1024;
+constexpr int kFixStack = 384;  // as the walk: 6 KB of LDS per wave leaves room for 16 waves per CU; the ball pruning keeps stacks far below
 
 struct HasTie {
   __host__ __device__ bool operator()(uint8_t t) const { return t != 0; }
@@ -1488,7 +1488,7 @@ void Engine::fix_ties(const SolveArgs &sa, tknnSolveInfo *info, hipStream_t s) {
     OWLMI_HIP(hipcub::DeviceSelect::Flagged(wave_ws_, tmp_bytes, iota, flags, slot_list_, d_count, (int)n, s));
     OWLMI_HIP(hipMemsetAsync(counters_ + kTieCounter + 1, 0, 2 * sizeof(unsigned long long), s));
     OWLMI_HIP(hipEventRecord(ev_a_, s));
-    launch((int)std::min<int64_t>((flagged + 3) / 4, (int64_t)prop.multiProcessorCount * 8), slot_list_, (int32_t)flagged);
+    launch((int)std::min<int64_t>((flagged + 3) / 4, (int64_t)prop.multiProcessorCount * 16), slot_list_, (int32_t)flagged);
     OWLMI_HIP(hipEventRecord(ev_b_, s));
     OWLMI_HIP(hipMemcpyAsync(h_counters_, counters_ + kTieCounter, 3 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
     OWLMI_HIP(hipStreamSynchronize(s));
