@@ -504,16 +504,16 @@ void Engine::solve(const SolveArgs &sa, int kernel, tknnSolveInfo *info, hipStre
   // Rows whose order depends on how bit-identical fp32 distances are ordered: every kernel lists by
   // (dist, index) and flags them in tie_; fix_ties redoes them in the reference's order, by the round in
   // which each neighbour was first a candidate (deviceCode.cu:77-85 -- lists persist over rounds).
-  OWLMI_HIP(hipMemsetAsync(tie_, 0, (size_t)bvh_.size(), s));
-  OWLMI_HIP(hipMemsetAsync(counters_ + kTieCounter, 0, 3 * sizeof(unsigned long long), s));
   tknnSolveInfo mine;
   std::memset(&mine, 0, sizeof mine);
   bool solved = false;
   if (kernel == TKNN_KERNEL_TEAM) {
-    solved = solve_team(sa, &mine, s);
-    if (!solved) kernel = TKNN_KERNEL_WAVE;  // (solve_team handles its own tail and returns true today)
+    solved = solve_team(sa, &mine, s);  // (resets tie_ and the tie counters together with its own state, one launch)
+    if (!solved) kernel = TKNN_KERNEL_WAVE;  // n >= 2^28
   }
   if (!solved) {
+    OWLMI_HIP(hipMemsetAsync(tie_, 0, (size_t)bvh_.size(), s));
+    OWLMI_HIP(hipMemsetAsync(counters_ + kTieCounter, 0, 3 * sizeof(unsigned long long), s));
     if (kernel == TKNN_KERNEL_WAVE)
       solve_wave(sa, &mine, s);
     else
