@@ -274,6 +274,7 @@ Engine::Engine() {
   OWLMI_HIP(hipGetDevice(&device_));
   OWLMI_HIP(hipEventCreate(&ev_a_));
   OWLMI_HIP(hipEventCreate(&ev_b_));
+  OWLMI_HIP(hipEventCreate(&ev_c_));
   OWLMI_HIP(hipMalloc((void **)&counters_, kCounters * sizeof(unsigned long long)));  // [16..23]: the team kernel's per-XCD packet counters; [32]: tie rows
   OWLMI_HIP(hipMalloc((void **)&tie_list_, kTieListCap * sizeof(int32_t)));
   OWLMI_HIP(hipHostMalloc((void **)&h_counters_, 16 * sizeof(unsigned long long)));
@@ -296,6 +297,7 @@ Engine::~Engine() {
   if (wave_ws_) (void)hipFree(wave_ws_);
   if (ev_a_) (void)hipEventDestroy(ev_a_);
   if (ev_b_) (void)hipEventDestroy(ev_b_);
+  if (ev_c_) (void)hipEventDestroy(ev_c_);
 }
 
 void Engine::set_halo(const float *d_xyz, const int32_t *d_ids, int64_t m, hipStream_t s) {
@@ -507,6 +509,7 @@ void Engine::solve(const SolveArgs &sa, int kernel, tknnSolveInfo *info, hipStre
   tknnSolveInfo mine;
   std::memset(&mine, 0, sizeof mine);
   bool solved = false;
+  ties_early_ = false;
   if (kernel == TKNN_KERNEL_TEAM) {
     solved = solve_team(sa, &mine, s);  // (resets tie_ and the tie counters together with its own state, one launch)
     if (!solved) kernel = TKNN_KERNEL_WAVE;  // n >= 2^28

@@ -72,6 +72,7 @@ class Engine {
   static bool team_kernel_supports(int k);
   // trueknn_team.hip: redo the rows flagged in tie_ with the reference's order of exact-distance ties
   void fix_ties(const SolveArgs &sa, tknnSolveInfo *info, hipStream_t s);
+  void launch_tie_fix(const SolveArgs &sa, const int32_t *slots, int32_t nslots, int blocks, hipStream_t s);
   int first_step_estimate(const SolveArgs &sa) const;
   float scene_[6] = {0, 0, 0, 0, 0, 0};  // bounds of the built point set (host copy)
 
@@ -93,7 +94,12 @@ class Engine {
   int64_t slot_list_cap_ = 0;
   unsigned long long *halo_mask_ = nullptr;  // per leaf block: peers it may have points for (+ 64 cursors)
   int64_t halo_mask_cap_ = 0;
-  hipEvent_t ev_a_ = nullptr, ev_b_ = nullptr;
+  hipEvent_t ev_a_ = nullptr, ev_b_ = nullptr, ev_c_ = nullptr;
+  // the packet kernel's solve launches the tie pass behind itself, before its one host round trip: set if
+  // that launch has seen every flagged row (no tail ran, the list held them all)
+  bool ties_early_ = false;
+  int64_t early_tie_rows_ = 0, early_tie_left_ = 0;
+  float early_tie_ms_ = 0;
 };
 
 }  // namespace owlmi

@@ -1450,8 +1450,7 @@ __global__ void __launch_bounds__(kTeamBlock) tie_fix_kernel(TeamArgs a, const i
 
 bool Engine::team_kernel_supports(int k) { return k >= 1 && k <= 64; }
 
-void Engine::fix_ties(const SolveArgs &sa, tknnSolveInfo *info, hipStream_t s) {
-  const int64_t n = bvh_.size();
+void Engine::launch_tie_fix(const SolveArgs &sa, const int32_t *slots, int32_t nslots, int blocks, hipStream_t s) {
   TeamArgs a;
   std::memset(&a, 0, sizeof a);
   a.bvh = bvh_.view();
@@ -1466,16 +1465,31 @@ void Engine::fix_ties(const SolveArgs &sa, tknnSolveInfo *info, hipStream_t s) {
   a.tie = tie_;
   a.tie_list = tie_list_;
   a.counters = counters_;
-  hipDeviceProp_t prop;
-  OWLMI_HIP(hipGetDeviceProperties(&prop, device_));
   using FixEntry = void (*)(TeamArgs, const int32_t *, int32_t);
   static const FixEntry entries[2][3] = {{tie_fix_kernel<false, 1>, tie_fix_kernel<false, 2>, tie_fix_kernel<false, 4>},
                                          {tie_fix_kernel<true, 1>, tie_fix_kernel<true, 2>, tie_fix_kernel<true, 4>}};
   const FixEntry entry = entries[halo_n_ > 0 ? 1 : 0][sa.k <= 16 ? 0 : (sa.k <= 32 ? 1 : 2)];
-  auto launch = [&](int blocks, const int32_t *slots, int32_t nslots) {
-    void *kargs[] = {(void *)&a, (void *)&slots, (void *)&nslots};
-    OWLMI_HIP(hipLaunchKernel((const void *)entry, dim3(blocks), dim3(kTeamBlock), kargs, 0, s));
-  };
+  void *kargs[] = {(void *)&a, (void *)&slots, (void *)&nslots};
+  OWLMI_HIP(hipLaunchKernel((const void *)entry, dim3(blocks), dim3(kTeamBlock), kargs, 0, s));
+}
+
+void Engine::fix_ties(const SolveArgs &sa, tknnSolveInfo *info, hipStream_t s) {
+  if (ties_early_) {  // solve_team's own launch has seen them all
+    if (early_tie_rows_ && getenv("TKNN_VERBOSE"))
+      fprintf(stderr, "[ties] %lld rows redone in the reference's tie order: %.3f ms, %lld left\n", (long long)early_tie_rows_, early_tie_ms_, (long long)early_tie_left_);
+    if (info) {
+      info->tie_rows = early_tie_rows_;
+      info->tie_rows_left = early_tie_left_;
+      info->tie_ms = early_tie_ms_;
+      info->solve_ms += early_tie_ms_;
+    }
+    return;
+  }
+  const int64_t n = bvh_.size();
+  hipDeviceProp_t prop;
+  OWLMI_HIP(hipGetDeviceProperties(&prop, device_));
+  auto launch = [&](int blocks, const int32_t *slots, int32_t nslots) { launch_tie_fix(sa, slots, nslots, blocks, s); };
+  OWLMI_HIP(hipMemsetAsync(counters_ + kTieCounter + 1, 0, 2 * sizeof(unsigned long long), s));  // work cursor, rows left
   // First go: the kernels' own list, count read on the device -- no host round trip before the launch;
   // the usual handful of rows (or none) costs one small launch behind the solve.
   OWLMI_HIP(hipEventRecord(ev_a_, s));
@@ -1663,10 +1677,21 @@ bool Engine::solve_team(const SolveArgs &sa, tknnSolveInfo *info, hipStream_t s)
   }
   OWLMI_HIP(hipGetLastError());
   OWLMI_HIP(hipEventRecord(ev_b_, s));
+  // the tie pass over the rows this kernel has flagged and listed, count read on the device: launched
+  // before the host knows anything, so the usual handful costs no round trip of its own
+  launch_tie_fix(sa, tie_list_, -1, std::min(prop.multiProcessorCount * 4, kTieListCap / 4), s);
+  OWLMI_HIP(hipEventRecord(ev_c_, s));
   OWLMI_HIP(hipMemcpyAsync(h_counters_, counters_, 10 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+  OWLMI_HIP(hipMemcpyAsync(h_counters_ + 10, counters_ + kTieCounter, 3 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
   OWLMI_HIP(hipStreamSynchronize(s));
   float ms = 0;
   OWLMI_HIP(hipEventElapsedTime(&ms, ev_a_, ev_b_));
+  if (h_counters_[8] == 0 && h_counters_[10] <= (unsigned long long)kTieListCap) {  // nothing handed over, every flagged row listed
+    ties_early_ = true;
+    early_tie_rows_ = (int64_t)h_counters_[10];
+    early_tie_left_ = (int64_t)h_counters_[12];
+    OWLMI_HIP(hipEventElapsedTime(&early_tie_ms_, ev_b_, ev_c_));
+  }
 #if TKNN_DIAG_BUILD
   if (getenv("TKNN_TEAM_DIAG")) {
     unsigned long long t[5];
