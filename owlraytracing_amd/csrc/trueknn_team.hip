@@ -237,6 +237,8 @@ template <bool SELECT, bool HALO, int NREG, bool FULL>
 __device__ __forceinline__ void team_pass(const TeamArgs &a, const TeamLds &L, int n_list, float r_inner, int m,
                                           const LbvhPoint *own_pts, const LbvhPoint *halo_pts, int lane) {
   const int team = lane >> 4, tl = lane & 15;
+  m = __builtin_amdgcn_readfirstlane(m);  // wave-uniform by construction; says so to the compiler (scalar branches on it)
+  n_list = __builtin_amdgcn_readfirstlane(n_list);
   for (int r0 = 0; r0 < n_list; r0 += 4) {
     const bool on = r0 + team < n_list;
     int qi = 0;
@@ -250,11 +252,10 @@ __device__ __forceinline__ void team_pass(const TeamArgs &a, const TeamLds &L, i
     uint32_t cnt_i0 = 0;  // inner level of a two-level COUNT step (m = levels served by this gather, wave-uniform)
     const int packed = __float_as_int(rec[7]);
     const int my_n = on ? (packed & 0xff) : 0;  // leaf blocks of my team's query
-    int steps = my_n;                                   // wave-uniform trip count: longest list of the 4 teams
-    steps = max(steps, (int)__builtin_amdgcn_readlane(my_n, 16));
-    steps = max(steps, (int)__builtin_amdgcn_readlane(my_n, 32));
-    steps = max(steps, (int)__builtin_amdgcn_readlane(my_n, 48));
-    steps = max((int)__builtin_amdgcn_readlane(my_n, 0), steps);
+    // wave-uniform trip count: longest list of the 4 teams -- from v_readlane values only, so that the
+    // compiler keeps it (and the loop tests below) in scalar registers
+    const int steps = max(max((int)__builtin_amdgcn_readlane(my_n, 0), (int)__builtin_amdgcn_readlane(my_n, 16)),
+                          max((int)__builtin_amdgcn_readlane(my_n, 32), (int)__builtin_amdgcn_readlane(my_n, 48)));
     if (TKNN_DIAG_BUILD && (a.diag & 16) && lane == 0) atomicAdd(&a.counters[15], (unsigned long long)steps);
     // my query's block entries, spread over the team's lanes: lane tl holds entries tl, tl+16, ...
     // (clamped to the last one; teams without a query read block 0 of the own tree and ignore it)
@@ -590,6 +591,11 @@ __global__ void __launch_bounds__(kTeamBlock) __attribute__((amdgpu_waves_per_eu
       PHASE_END(4);
       // ---- 1. query records, conservative query boxes ---------------------------------------
       // This step serves levels level .. level+m-1 with ONE gather at the outermost radius.
+      // (level, step and r are the same in every lane; readfirstlane says so to the compiler, which then
+      // keeps them and everything derived from them in scalar registers and branches on them without exec masks)
+      level = __builtin_amdgcn_readfirstlane(level);
+      step = __builtin_amdgcn_readfirstlane(step);
+      r = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(r)));
       int m = step < 1 ? 1 : (step > kMaxStep ? kMaxStep : step);
       if (level + m > a.max_rounds) m = a.max_rounds - level;
       const float r_in0 = r;                        // radius of the inner level of a two-level step
