@@ -53,3 +53,32 @@ def test_product_package_never_imports_the_oracle():
                 src = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f
                 assert not re.search(r'#include\s+[<"].*oracle', src), f
+
+
+def test_ctypes_structs_have_the_header_layout(tmp_path):
+    """Sizes and field offsets of the ctypes mirrors against include/owlknn.h compiled by gcc as C99."""
+    import ctypes
+    import subprocess
+    pairs = {"tknnSolveInfo": _lib.SolveInfo, "tknnSolveOptions": _lib.SolveOptions,
+             "tknnDbscanInfo": _lib.DbscanInfo, "tknnBuildInfo": _lib.BuildInfo}
+    lines = ["#include <stdio.h>", "#include <stddef.h>", '#include "owlknn.h"', "int main(void) {"]
+    for cname, cls in pairs.items():
+        lines.append('  printf("%s size %%zu\\n", sizeof(%s));' % (cname, cname))
+        for field, _ in cls._fields_:
+            lines.append('  printf("%s %s %%zu\\n", offsetof(%s, %s));' % (cname, field, cname, field))
+    lines += ["  return 0;", "}"]
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-std=c99", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout
+    seen = 0
+    for line in out.splitlines():
+        cname, what, value = line.split()
+        cls = pairs[cname]
+        if what == "size":
+            assert ctypes.sizeof(cls) == int(value), cname
+        else:
+            assert getattr(cls, what).offset == int(value), (cname, what)
+        seen += 1
+    assert seen == sum(len(c._fields_) + 1 for c in pairs.values())
