@@ -183,3 +183,68 @@ def test_start_radius_sampler_is_seeded_and_sane():
     assert abs(r - d.min()) < 1e-12
     # a solve started there terminates in a handful of rounds on uniform data
     assert oracle.trueknn(xyz, 5, r)["rounds"] <= 8
+
+
+def test_tie_flag_bound_never_misses_a_cross_round_tie():
+    """The team kernels drop a tie from the tie pass when `tie_may_straddle` (trueknn_team.hip) says
+    that two candidates at that fp32 distance cannot have become candidates in different rounds.
+    Restated here in float32 and checked against the literal box test of every round
+    (deviceCode.cu:38-56): whenever two points at bit-identical distances from a query have
+    different first rounds, the bound must have said "may straddle" -- in 3-D, in a plane (span
+    sqrt(2)) and on a line, from far below the start radius to beyond the last one."""
+    f = np.float32
+
+    def may_straddle(d, r0, r_last, qmax, span):
+        r = f(r0)
+        while True:
+            mg = f(f(qmax + f(f(2) * r)) * f(4.76837158203125e-07))
+            if d <= f(f(r - mg) * f(0.99999)):
+                return False
+            if d <= f(f(r + mg) * f(span)):
+                return True
+            if not (r < r_last):
+                return True
+            r = f(r * f(2))
+
+    def first_round(c, q, r0, rounds):
+        r = f(r0)
+        for lvl in range(rounds):
+            lo, hi = (c - r).astype(f), (c + r).astype(f)
+            if np.all((np.minimum(lo, hi) <= q) & (q <= np.maximum(lo, hi))):
+                return lvl
+            r = f(r * f(2))
+        return rounds
+
+    # integer triples with equal Euclidean and different Chebyshev norms; scaled by powers of two the
+    # offsets, the differences and the squared distances are exact in fp32
+    groups = [[(3, 4, 0), (5, 0, 0), (0, 3, 4)], [(1, 2, 2), (3, 0, 0), (2, 2, 1)], [(2, 3, 6), (7, 0, 0), (6, 2, 3)],
+              [(1, 4, 8), (9, 0, 0), (4, 4, 7)], [(2, 6, 9), (11, 0, 0), (6, 6, 7)], [(10, 10, 5), (15, 0, 0), (2, 10, 11)]]
+    planar = [[(3, 4, 0), (5, 0, 0), (4, 3, 0)], [(5, 12, 0), (13, 0, 0)], [(7, 24, 0), (25, 0, 0), (15, 20, 0)]]
+    rng = np.random.default_rng(11)
+    straddling = checked = 0
+    for span, sets, dims in ((1.73206, groups, 3), (1.41422, planar, 2)):
+        for _ in range(4000):
+            grp = sets[rng.integers(len(sets))]
+            scale = f(2.0 ** rng.integers(-12, 3))
+            q = (rng.integers(-64, 64, 3) * scale * f(8)).astype(f)
+            if dims == 2:
+                q[2] = f(0.25)
+            d_true = f(np.sqrt(f(sum(v * v for v in grp[0])))) * scale
+            r0 = f(d_true * f(2.0 ** rng.uniform(-3.5, 1.2)))
+            pts = []
+            for t in grp:
+                sign = rng.choice([-1, 1], 3)
+                perm = rng.permutation(3) if dims == 3 else np.array([*rng.permutation(2), 2])
+                off = (np.array(t, f)[perm] * sign * scale).astype(f)
+                pts.append((q + off).astype(f))
+            dist = [np.sqrt(((p - q).astype(f) ** 2).sum(dtype=f), dtype=f) for p in pts]
+            assert all(x.view(np.int32) == dist[0].view(np.int32) for x in dist)
+            firsts = [first_round(p, q, r0, 12) for p in pts]
+            last = max(firsts)  # the query finishes no earlier than the round that sees all of them
+            r_last = f(r0 * f(2.0 ** last))
+            qmax = f(np.abs(q).max())
+            checked += 1
+            if len(set(firsts)) > 1:
+                straddling += 1
+                assert may_straddle(dist[0], r0, r_last, qmax, span), (q, pts, r0, firsts)
+    assert straddling > 500 and checked == 8000
