@@ -185,3 +185,148 @@ int dbref_dbscan(const float *xyz, int64_t n, float eps, int min_pts, int32_t *l
   free(g.items);
   return nclusters;
 }
+
+
+/* ---- the same spec on all host cores: the CPU baseline bench.py times beside RT-DBSCAN ----------------
+ * ("threaded grid DBSCAN on the GPU box").  Same grid, same distance
+ * arithmetic, same labelling rule as dbref_dbscan above, so the two agree label for label
+ * (tests/test_dbscan.py); what differs is the schedule: core flags stop counting at minPts, unions run
+ * concurrently on a lock-free union-find (a root only ever gets a smaller parent, so the component's
+ * root is its smallest core index whatever the interleaving), borders and the ranking are parallel.
+ * seconds (may be NULL): [0] grid, [1] core flags, [2] unions, [3] labels. */
+#include <omp.h>
+
+static int64_t db_count_upto(const db_grid *g, const float *xyz, int32_t q, float eps, int64_t stop) {
+  const float *c = xyz + 3 * (int64_t)q;
+  double reach = (double)eps * 1.0001 + 1e-30;
+  int c0[3], c1[3];
+  for (int a = 0; a < 3; a++) {
+    double slack = reach + 1e-6 * fabs((double)c[a]);
+    c0[a] = db_cell(g, a, (double)c[a] - slack);
+    c1[a] = db_cell(g, a, (double)c[a] + slack);
+  }
+  int64_t m = 0;
+  for (int z = c0[2]; z <= c1[2]; z++)
+    for (int y = c0[1]; y <= c1[1]; y++)
+      for (int x = c0[0]; x <= c1[0]; x++) {
+        int64_t cell = ((int64_t)z * g->dim[1] + y) * g->dim[0] + x;
+        for (int64_t s = g->start[cell]; s < g->start[cell + 1]; s++)
+          if (db_dist(xyz + 3 * (int64_t)g->items[s], c) <= eps && ++m >= stop) return m;
+      }
+  return m;
+}
+
+static inline int32_t db_find_mt(int32_t *parent, int32_t x) {
+  for (;;) {
+    int32_t p = __atomic_load_n(&parent[x], __ATOMIC_RELAXED);
+    if (p == x) return x;
+    int32_t gp = __atomic_load_n(&parent[p], __ATOMIC_RELAXED);
+    if (gp != p) __atomic_compare_exchange_n(&parent[x], &p, gp, 0, __ATOMIC_RELAXED, __ATOMIC_RELAXED); /* halving */
+    x = p;
+  }
+}
+
+static void db_unite_mt(int32_t *parent, int32_t a, int32_t b) {
+  for (;;) {
+    a = db_find_mt(parent, a);
+    b = db_find_mt(parent, b);
+    if (a == b) return;
+    if (a > b) {
+      int32_t t = a;
+      a = b;
+      b = t;
+    }
+    int32_t expect = b; /* b is a root: hang it under the smaller root a */
+    if (__atomic_compare_exchange_n(&parent[b], &expect, a, 0, __ATOMIC_ACQ_REL, __ATOMIC_RELAXED)) return;
+  }
+}
+
+int dbref_dbscan_mt(const float *xyz, int64_t n, float eps, int min_pts, int32_t *labels, uint8_t *core,
+                    double *seconds) {
+  if (!xyz || !labels || !core || n <= 0 || !(eps > 0) || min_pts < 1) return -1;
+  double t0 = omp_get_wtime();
+  db_grid g;
+  if (db_grid_build(&g, xyz, n, (double)eps)) return -2;
+  int32_t *parent = (int32_t *)malloc((size_t)n * sizeof(int32_t));
+  int32_t *rank = (int32_t *)malloc((size_t)n * sizeof(int32_t));
+  if (!parent || !rank) return -2;
+  double t1 = omp_get_wtime();
+#pragma omp parallel for schedule(dynamic, 1024)
+  for (int64_t i = 0; i < n; i++) {
+    core[i] = db_count_upto(&g, xyz, (int32_t)i, eps, min_pts) >= min_pts;
+    parent[i] = (int32_t)i;
+  }
+  double t2 = omp_get_wtime();
+#pragma omp parallel for schedule(dynamic, 256)
+  for (int64_t i = 0; i < n; i++) {
+    if (!core[i]) continue;
+    const float *c = xyz + 3 * i;
+    double reach = (double)eps * 1.0001 + 1e-30;
+    int c0[3], c1[3];
+    for (int a = 0; a < 3; a++) {
+      double slack = reach + 1e-6 * fabs((double)c[a]);
+      c0[a] = db_cell(&g, a, (double)c[a] - slack);
+      c1[a] = db_cell(&g, a, (double)c[a] + slack);
+    }
+    int32_t mine = db_find_mt(parent, (int32_t)i);
+    for (int z = c0[2]; z <= c1[2]; z++)
+      for (int y = c0[1]; y <= c1[1]; y++)
+        for (int x = c0[0]; x <= c1[0]; x++) {
+          int64_t cell = ((int64_t)z * g.dim[1] + y) * g.dim[0] + x;
+          for (int64_t s = g.start[cell]; s < g.start[cell + 1]; s++) {
+            int32_t p = g.items[s];
+            /* each pair once (from its larger index); a cached root spares the distance for pairs already joined */
+            if (p >= i || !core[p]) continue;
+            if (__atomic_load_n(&parent[p], __ATOMIC_RELAXED) == mine) continue;
+            if (db_dist(xyz + 3 * (int64_t)p, c) <= eps) {
+              db_unite_mt(parent, (int32_t)i, p);
+              mine = db_find_mt(parent, (int32_t)i);
+            }
+          }
+        }
+  }
+  double t3 = omp_get_wtime();
+  /* roots in ascending index order get labels 0,1,... (serial prefix over n flags: memory-bound, short) */
+  int32_t nclusters = 0;
+  for (int64_t i = 0; i < n; i++) rank[i] = (core[i] && parent[i] == (int32_t)i) ? nclusters++ : -1;
+#pragma omp parallel for schedule(dynamic, 1024)
+  for (int64_t i = 0; i < n; i++) {
+    if (core[i]) {
+      labels[i] = rank[db_find_mt(parent, (int32_t)i)];
+      continue;
+    }
+    const float *c = xyz + 3 * i;
+    double reach = (double)eps * 1.0001 + 1e-30;
+    int c0[3], c1[3];
+    for (int a = 0; a < 3; a++) {
+      double slack = reach + 1e-6 * fabs((double)c[a]);
+      c0[a] = db_cell(&g, a, (double)c[a] - slack);
+      c1[a] = db_cell(&g, a, (double)c[a] + slack);
+    }
+    int32_t best = -1;
+    for (int z = c0[2]; z <= c1[2]; z++)
+      for (int y = c0[1]; y <= c1[1]; y++)
+        for (int x = c0[0]; x <= c1[0]; x++) {
+          int64_t cell = ((int64_t)z * g.dim[1] + y) * g.dim[0] + x;
+          for (int64_t s = g.start[cell]; s < g.start[cell + 1]; s++) {
+            int32_t p = g.items[s];
+            if (!core[p] || db_dist(xyz + 3 * (int64_t)p, c) > eps) continue;
+            int32_t r = db_find_mt(parent, p);
+            if (best < 0 || r < best) best = r;
+          }
+        }
+    labels[i] = best < 0 ? -1 : rank[best];
+  }
+  double t4 = omp_get_wtime();
+  if (seconds) {
+    seconds[0] = t1 - t0;
+    seconds[1] = t2 - t1;
+    seconds[2] = t3 - t2;
+    seconds[3] = t4 - t3;
+  }
+  free(rank);
+  free(parent);
+  free(g.start);
+  free(g.items);
+  return nclusters;
+}

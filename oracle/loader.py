@@ -62,6 +62,9 @@ def _load():
         lib.dbref_dbscan.restype = ctypes.c_int
         lib.dbref_dbscan.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_float, ctypes.c_int,
                                      ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+        lib.dbref_dbscan_mt.restype = ctypes.c_int
+        lib.dbref_dbscan_mt.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_float, ctypes.c_int,
+                                        ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
         assert lib.tkref_sizeof_neigh() == NEIGH_DTYPE.itemsize
         _lib = lib
     return _lib
@@ -155,3 +158,20 @@ def dbscan(xyz, eps, min_pts):
     if rc < 0:
         raise OracleError("dbscan oracle failed: %d" % rc)
     return {"labels": labels, "core": core.astype(bool), "counts": counts, "clusters": rc}
+
+
+def dbscan_threaded(xyz, eps, min_pts):
+    """The same spec on all host cores (dbref_dbscan_mt): what bench.py times as RT-DBSCAN's CPU
+    baseline.  dict(labels, core, clusters, seconds=[grid, core flags, unions, labels])."""
+    lib = _load()
+    xyz = _points(xyz)
+    n = len(xyz)
+    labels = np.empty(n, np.int32)
+    core = np.empty(n, np.uint8)
+    seconds = np.zeros(4, np.float64)
+    rc = lib.dbref_dbscan_mt(xyz.ctypes.data, n, ctypes.c_float(eps), int(min_pts), labels.ctypes.data,
+                             core.ctypes.data, seconds.ctypes.data)
+    if rc < 0:
+        raise OracleError("threaded dbscan failed: %d" % rc)
+    return {"labels": labels, "core": core.astype(bool), "clusters": rc, "seconds": seconds}
+

@@ -52,6 +52,7 @@ class Lbvh {
   int32_t *nan_count() const { return reinterpret_cast<int32_t *>(scene_ + 6); }
   int64_t size() const { return n_; }
   bool built() const { return built_; }
+  void clear() { built_ = false; }  // marks the tree unusable (a failed rebuild); memory stays reserved
   bool has_points() const { return points_ != nullptr && point_mode_; }
   size_t device_bytes() const { return bytes_; }
 

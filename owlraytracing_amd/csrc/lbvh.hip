@@ -473,6 +473,7 @@ void Lbvh::fit(hipStream_t stream) {
 
 void Lbvh::build_from_points(const float *d_xyz, int64_t n, hipStream_t stream, const int32_t *d_ids) {
   if (n <= 0 || n >= 0x7fffffffLL) throw HipError{"Lbvh: primitive count out of range"};
+  built_ = false;  // until the last launch below has been issued without an error
   reserve(n);
   n_ = n;
   point_mode_ = true;

@@ -173,12 +173,20 @@ struct SBTObject : Object {
 struct Module : Object {
   Module(Context *c, const char *code_) : Object(c, Kind::Module), code(code_) {}
   ~Module() override {
+    if (params_free) (void)hipEventDestroy(params_free);
     if (mod) (void)hipModuleUnload(mod);
   }
   const char *code;
   hipModule_t mod = nullptr;
   hipDeviceptr_t params_ptr = nullptr;  // `optixLaunchParams`, if the module defines it
   size_t params_bytes = 0;
+  // `optixLaunchParams` is ONE global of the user's code object, while every OWLParams launches on a
+  // stream of its own (reference: a device buffer per LaunchParams, LaunchParams.cpp:38-49, so async
+  // launches with different params may overlap there).  Here the next upload into the global waits
+  // for the last kernel that reads it, whatever stream that ran on.
+  hipEvent_t params_free = nullptr;
+  hipStream_t params_stream = nullptr;
+  bool params_in_use = false;
   void load() {
     if (mod) return;
     if (!code) fail("owlModuleCreate was given a NULL code pointer");
@@ -701,6 +709,7 @@ void launch(RayGen &rg, int dx, int dy, Params *lp, bool sync) {
     std::vector<uint8_t> &blob = lp->staging;
     lp->materialise(blob);
     if (blob.size() > m.params_bytes) fail("launch params struct is larger than the module's optixLaunchParams");
+    if (m.params_in_use && m.params_stream != s) OWL_HIP(hipStreamWaitEvent(s, m.params_free, 0));
     OWL_HIP(hipMemcpyAsync(m.params_ptr, blob.data(), blob.size(), hipMemcpyHostToDevice, s));
   }
   // managed buffers may have been paged to the host by the application between launches
@@ -717,6 +726,13 @@ void launch(RayGen &rg, int dx, int dy, Params *lp, bool sync) {
   desc.miss = (const rec::MissRecord *)c.miss_records.ptr;
   void *args[] = {(void *)&desc};
   launch_kernel(rg.kernel, (uint64_t)dx * (uint64_t)dy, rec::kRaygenBlock, args, s);
+  if (lp) {
+    Module &m = *rg.module;
+    if (!m.params_free) OWL_HIP(hipEventCreateWithFlags(&m.params_free, hipEventDisableTiming));
+    OWL_HIP(hipEventRecord(m.params_free, s));
+    m.params_stream = s;
+    m.params_in_use = true;
+  }
   if (sync) OWL_HIP(hipStreamSynchronize(s));
 }
 

@@ -278,6 +278,7 @@ Engine::Engine() {
   OWLMI_HIP(hipMalloc((void **)&counters_, kCounters * sizeof(unsigned long long)));  // [16..23]: the team kernel's per-XCD packet counters; [32]: tie rows
   OWLMI_HIP(hipMalloc((void **)&tie_list_, kTieListCap * sizeof(int32_t)));
   OWLMI_HIP(hipHostMalloc((void **)&h_counters_, 16 * sizeof(unsigned long long)));
+  if (const char *e = getenv("TKNN_WAVE_FORCE_REDO")) wave_force_redo_ = atoi(e) != 0;
   if (const char *e = getenv("TKNN_LEAF_MAX")) {
     int v = atoi(e);
     if (v >= 1 && v <= 64) wave_leaf_max_ = v;
@@ -318,9 +319,10 @@ LbvhView Engine::halo_view() const {
 void Engine::build(const float *d_xyz, const int32_t *d_ids, int64_t n, tknnBuildInfo *info, hipStream_t s) {
   OWLMI_HIP(hipEventRecord(ev_a_, s));
   halo_n_ = 0;
-  bvh_.build_from_points(d_xyz, n, s, d_ids);
-  OWLMI_HIP(hipEventRecord(ev_b_, s));
+  // Per-slot solve state first: if one of these allocations fails (a 100 M-point rebuild on a full
+  // card) the engine must not be left "built" with null state arrays behind a stale capacity.
   if (n > state_cap_) {
+    state_cap_ = 0;
     if (done_) (void)hipFree(done_);
     if (isect_sorted_) (void)hipFree(isect_sorted_);
     if (next_level_) (void)hipFree(next_level_);
@@ -329,12 +331,24 @@ void Engine::build(const float *d_xyz, const int32_t *d_ids, int64_t n, tknnBuil
     done_ = nullptr;
     isect_sorted_ = nullptr;
     next_level_ = nullptr;
-    OWLMI_HIP(hipMalloc((void **)&done_, (size_t)n));
-    OWLMI_HIP(hipMalloc((void **)&isect_sorted_, (size_t)n * sizeof(int64_t)));
-    OWLMI_HIP(hipMalloc((void **)&next_level_, (size_t)n * sizeof(int32_t)));
-    OWLMI_HIP(hipMalloc((void **)&tie_, (size_t)n));
+    try {
+      OWLMI_HIP(hipMalloc((void **)&done_, (size_t)n));
+      OWLMI_HIP(hipMalloc((void **)&isect_sorted_, (size_t)n * sizeof(int64_t)));
+      OWLMI_HIP(hipMalloc((void **)&next_level_, (size_t)n * sizeof(int32_t)));
+      OWLMI_HIP(hipMalloc((void **)&tie_, (size_t)n));
+    } catch (...) {
+      bvh_.clear();  // unbuilt: tknnSolve then answers TKNN_E_STATE instead of launching on null arrays
+      throw;
+    }
     state_cap_ = n;
   }
+  try {
+    bvh_.build_from_points(d_xyz, n, s, d_ids);
+  } catch (...) {
+    bvh_.clear();
+    throw;
+  }
+  OWLMI_HIP(hipEventRecord(ev_b_, s));
   OWLMI_HIP(hipMemcpyAsync(scene_, bvh_.scene_device(), 6 * sizeof(float), hipMemcpyDeviceToHost, s));
   OWLMI_HIP(hipStreamSynchronize(s));
   OWLMI_HIP(hipEventSynchronize(ev_b_));
@@ -559,6 +573,27 @@ static int guarded(F &&f) {
   }
 }
 
+// Every engine call runs on the device the engine was created on (the caller's current device at
+// tknnCreate), whatever device is current in the calling thread now; the caller's choice is restored.
+struct DeviceScope {
+  int prev = -1, want;
+  explicit DeviceScope(int device) : want(device) {
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    if (prev != want && hipSetDevice(want) != hipSuccess) throw owlmi::HipError{"hipSetDevice(engine's device) failed"};
+  }
+  ~DeviceScope() {
+    if (prev >= 0 && prev != want) (void)hipSetDevice(prev);
+  }
+};
+
+template <typename F>
+static int guarded_on(tknnEngine e, F &&f) {
+  return guarded([&] {
+    DeviceScope scope(e->impl.device());
+    f();
+  });
+}
+
 extern "C" {
 
 const char *tknnLastError(void) { return g_last_error.c_str(); }
@@ -583,7 +618,15 @@ int tknnCreate(tknnEngine *out) {
   });
 }
 
-void tknnDestroy(tknnEngine e) { delete e; }
+void tknnDestroy(tknnEngine e) {
+  if (!e) return;
+  try {
+    DeviceScope scope(e->impl.device());
+    delete e;
+  } catch (...) {
+    delete e;
+  }
+}
 
 int tknnBuildIds(tknnEngine e, const float *d_xyz, const int32_t *d_ids, int64_t n, tknnBuildInfo *info,
                  void *stream) {
@@ -591,7 +634,7 @@ int tknnBuildIds(tknnEngine e, const float *d_xyz, const int32_t *d_ids, int64_t
     g_last_error = "tknnBuild: need an engine, a device pointer and 0 < n < 2^31-1";
     return TKNN_E_ARG;
   }
-  return guarded([&] { e->impl.build(d_xyz, d_ids, n, info, (hipStream_t)stream); });
+  return guarded_on(e, [&] { e->impl.build(d_xyz, d_ids, n, info, (hipStream_t)stream); });
 }
 
 int tknnBuild(tknnEngine e, const float *d_xyz, int64_t n, tknnBuildInfo *info, void *stream) {
@@ -603,7 +646,7 @@ int tknnSetHalo(tknnEngine e, const float *d_xyz, const int32_t *d_ids, int64_t 
     g_last_error = "tknnSetHalo: need an engine and, for m > 0, device pointers to points and ids";
     return TKNN_E_ARG;
   }
-  return guarded([&] {
+  return guarded_on(e, [&] {
     if (!e->impl.built()) throw owlmi::ArgError{TKNN_E_STATE, "tknnSetHalo: call tknnBuild first"};
     e->impl.set_halo(d_xyz, d_ids, m, (hipStream_t)stream);
   });
@@ -615,7 +658,7 @@ int tknnHaloSelect(tknnEngine e, const float *d_boxes, const int32_t *d_box_peer
     g_last_error = "tknnHaloSelect: need boxes with their peers, and counts (count pass) or offsets + rows (write pass)";
     return TKNN_E_ARG;
   }
-  return guarded([&] {
+  return guarded_on(e, [&] {
     if (!e->impl.built()) throw owlmi::ArgError{TKNN_E_STATE, "tknnHaloSelect: call tknnBuild first"};
     e->impl.halo_select(d_boxes, d_box_peer, nboxes, npeers, d_counts, d_offsets, d_rows, (hipStream_t)stream);
   });
@@ -647,7 +690,7 @@ int tknnSolveEx(tknnEngine e, const tknnSolveOptions *options, tknnSolveInfo *in
   float *d_dist = options->d_dist;
   int64_t *d_intersections = options->d_intersections;
   tknnNeigh *d_fb = options->d_fb;
-  return guarded([&] {
+  return guarded_on(e, [&] {
     if (!e->impl.built()) throw owlmi::ArgError{TKNN_E_STATE, "tknnSolve: call tknnBuild first"};
     if (k <= 0) throw owlmi::ArgError{TKNN_E_ARG, "tknnSolve: k must be positive"};
     if (k > TKNN_MAX_K) throw owlmi::ArgError{TKNN_E_UNSUPPORTED, "tknnSolve: k exceeds TKNN_MAX_K"};
@@ -679,7 +722,7 @@ int tknnRepairExact(tknnEngine e, int k, float start_radius, const int32_t *d_le
     g_last_error = "tknnRepairExact: engine, levels, idx and dist are required";
     return TKNN_E_ARG;
   }
-  return guarded([&] {
+  return guarded_on(e, [&] {
     if (!e->impl.built()) throw owlmi::ArgError{TKNN_E_STATE, "tknnRepairExact: call tknnBuild first"};
     if (k <= 0 || k > TKNN_MAX_K) throw owlmi::ArgError{TKNN_E_ARG, "tknnRepairExact: k out of range"};
     if (!(start_radius > 0.f) || !std::isfinite(start_radius))
@@ -695,7 +738,7 @@ int tknnDbscan(tknnEngine e, float eps, int min_pts, int32_t *d_labels, uint8_t 
     g_last_error = "tknnDbscan: engine or labels pointer is NULL";
     return TKNN_E_ARG;
   }
-  return guarded([&] {
+  return guarded_on(e, [&] {
     if (!e->impl.built()) throw owlmi::ArgError{TKNN_E_STATE, "tknnDbscan: call tknnBuild first"};
     if (!(eps > 0.f) || !std::isfinite(eps)) throw owlmi::ArgError{TKNN_E_ARG, "tknnDbscan: eps must be finite and > 0"};
     if (min_pts < 1) throw owlmi::ArgError{TKNN_E_ARG, "tknnDbscan: min_pts must be >= 1"};
@@ -709,7 +752,7 @@ int tknnDbscanAssign(tknnEngine e, float eps, const int32_t *d_core_label, int32
     g_last_error = "tknnDbscanAssign: engine, core labels or labels pointer is NULL";
     return TKNN_E_ARG;
   }
-  return guarded([&] {
+  return guarded_on(e, [&] {
     if (!e->impl.built()) throw owlmi::ArgError{TKNN_E_STATE, "tknnDbscanAssign: call tknnBuild first"};
     if (!(eps > 0.f) || !std::isfinite(eps)) throw owlmi::ArgError{TKNN_E_ARG, "tknnDbscanAssign: eps must be finite and > 0"};
     e->impl.dbscan(eps, 1, d_labels, nullptr, nullptr, info, (hipStream_t)stream, d_core_label);
@@ -722,7 +765,7 @@ int tknnExportTree(tknnEngine e, void *nodes, int32_t *rope_node, int32_t *rope_
     g_last_error = "tknnExportTree: engine is NULL";
     return TKNN_E_ARG;
   }
-  return guarded([&] {
+  return guarded_on(e, [&] {
     if (!e->impl.built()) throw owlmi::ArgError{TKNN_E_STATE, "tknnExportTree: call tknnBuild first"};
     e->impl.tree().download((LbvhNode *)nodes, rope_node, rope_leaf, prim_id, (hipStream_t)stream);
   });

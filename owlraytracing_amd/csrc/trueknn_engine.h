@@ -57,6 +57,7 @@ class Engine {
   void dbscan(float eps, int min_pts, int32_t *d_labels, uint8_t *d_core, int32_t *d_counts, tknnDbscanInfo *info,
               hipStream_t s, const int32_t *core_label = nullptr);
   bool built() const { return bvh_.built(); }
+  int device() const { return device_; }
   int64_t size() const { return bvh_.size(); }
   const Lbvh &tree() const { return bvh_; }
 
@@ -72,7 +73,8 @@ class Engine {
   static bool team_kernel_supports(int k);
   // trueknn_team.hip: redo the rows flagged in tie_ with the reference's order of exact-distance ties
   void fix_ties(const SolveArgs &sa, tknnSolveInfo *info, hipStream_t s);
-  void launch_tie_fix(const SolveArgs &sa, const int32_t *slots, int32_t nslots, int blocks, hipStream_t s);
+  void launch_tie_fix(const SolveArgs &sa, const int32_t *slots, int32_t nslots, int blocks, hipStream_t s,
+                      const int32_t *d_slot_count = nullptr);
   int first_step_estimate(const SolveArgs &sa) const;
   float scene_[6] = {0, 0, 0, 0, 0, 0};  // bounds of the built point set (host copy)
 
@@ -89,6 +91,7 @@ class Engine {
   unsigned long long *counters_ = nullptr, *h_counters_ = nullptr;
   void *wave_ws_ = nullptr;
   size_t wave_ws_bytes_ = 0;
+  bool wave_force_redo_ = false;  // TKNN_WAVE_FORCE_REDO (tests): treat every wave-kernel solve as if its LDS stack had overflowed
   int wave_leaf_max_ = 16;  // subtrees of at most this many points are streamed as one range (TKNN_LEAF_MAX)
   int32_t *slot_list_ = nullptr;  // compact list of the sorted slots the team kernel handed over (+ its length)
   int64_t slot_list_cap_ = 0;

@@ -87,7 +87,8 @@ struct TeamArgs {
   int allow_unfinished;
   int first_step;  // levels the first gather of every packet serves (density estimate, 1..kMaxStep)
   float tie_span;  // sqrt(number of axes along which the points differ), rounded up: d <= tie_span * Chebyshev distance
-  int diag;        // TKNN_DIAG_BUILD only: 1 skip inserts, 2 skip SELECT passes, 4 skip COUNT passes, 8 skip per-block query tests
+  int diag;        // TKNN_DIAG_BUILD only: 1 skip inserts, 2 skip SELECT passes, 4 skip COUNT passes, 8 skip per-block query tests,
+                   // 16 / 32 step and gather statistics (atomics: slow), 64 every block visit of a query reads its first listed block
   int32_t ngroups;
   int32_t *out_idx;
   float *out_dist;
@@ -103,6 +104,7 @@ struct TeamArgs {
   // the list (entry k: the best candidate left out); tie_fix_kernel redoes them in the reference's tie order
   uint8_t *tie;
   int32_t *tie_list;
+  const int32_t *slot_count;  // tie_fix_kernel, nslots == -2: length of `slots` as hipCUB's select wrote it (device side)
   // [0] (unused here) [16..23] per-XCD packet counters [1] max levels [2] node tests [3] point tests [4] sum isect
   // [5] error flags (1 max_rounds) [6] sum levels [7] unfinished [8] handed over [9] min hand-over level
   unsigned long long *counters;
@@ -176,9 +178,20 @@ __device__ __forceinline__ uint32_t t_count(uint32_t acc, unsigned long long mas
   return out;
 }
 
+// the same, and `keep` stays live (in its register) up to here at no cost: the COUNT pass never reads a
+// block's id word, and the allocator would reuse the fourth register of a load's destination tuple as a
+// temporary while the load is in flight -- a write-after-write hazard the compiler covers with
+// s_waitcnt vmcnt(0), which drains the whole ring
+__device__ __forceinline__ uint32_t t_count_keep(uint32_t acc, unsigned long long mask, int32_t keep) {
+  uint32_t out;
+  asm("v_addc_co_u32_e64 %0, vcc, 0, %1, %2" : "=v"(out) : "v"(acc), "s"(mask), "v"(keep) : "vcc");
+  return out;
+}
+
 // squared distance from the three differences: knn_dist2's expression ((x*x) + (y*y)) + (z*z),
 // x and y squared in one packed instruction
 typedef float t_float2 __attribute__((ext_vector_type(2)));
+typedef float t_point4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ float t_dist2(float dx, float dy, float dz) {
 #pragma clang fp contract(off)
   const t_float2 dxy = {dx, dy};
@@ -286,7 +299,8 @@ __device__ __forceinline__ void team_pass(const TeamArgs &a, const TeamLds &L, i
     };
     auto list_entry = [&](int pos) -> int32_t {
       const int at = min(max(list_pos(pos), 0), kMaxPerQuery - 1);
-      const int32_t e = L.blk[mine[at]];
+      int32_t e = L.blk[mine[at]];
+      if (TKNN_DIAG_BUILD && (a.diag & 64)) e = L.blk[mine[0]];  // every visit reads one and the same block: what do cache misses cost?
       return resolve_entry<HALO>(pos <= last ? e : nan_block);
     };
     e0 = list_entry(tl);
@@ -329,7 +343,7 @@ __device__ __forceinline__ void team_pass(const TeamArgs &a, const TeamLds &L, i
       unsigned long long in_m = __ballot(t <= in_below);
       const unsigned long long maybe_m = __ballot(t <= in_upto) & ~in_m;
       if (maybe_m) in_m |= maybe_m & __ballot(knn_in_box(p.x, p.y, p.z, t_r, t_qx, t_qy, t_qz));
-      cnt = t_count(cnt, in_m);
+      cnt = t_count_keep(cnt, in_m, p.id);
       if (!SELECT && m > 1) {
         unsigned long long in0_m = __ballot(t <= i0_below);
         const unsigned long long maybe0_m = __ballot(t <= i0_upto) & ~in0_m;
@@ -386,22 +400,33 @@ __device__ __forceinline__ void team_pass(const TeamArgs &a, const TeamLds &L, i
         }
       }
     };
-    // ping-pong over two named buffers: the next block is in flight while this one is tested, and
-    // no register is copied between iterations.  Loads are unconditional (indices past the list
-    // name some valid block, see above).  The list is walked in chunks of 16 entries = one entry
-    // register, so picking the register (a scalar branch chain) happens once per chunk and an
-    // entry costs one select + one cross-lane read.
+    // A ring of four block buffers: while one block is tested the next three are in flight (a leaf block
+    // comes from the XCD's L2 most of the time: several hundred cycles, against some fifty of work per
+    // block), and the cross-lane reads that fetch the NEXT group's addresses are issued a whole group
+    // ahead, so neither the LDS crossbar nor the cache is waited for in the loop.  Loads are
+    // unconditional and consumed in strict rotation (the compiler's s_waitcnt vmcnt(N) then counts
+    // exactly); visit positions past the longest list of the four teams name the all-NaN block.
     const LbvhPoint *own_base = a.bvh.points;  // wave-uniform
     const uint32_t lane_bytes = (uint32_t)tl * (uint32_t)sizeof(LbvhPoint);
-    LbvhPoint pa = load_block_point<HALO>(own_pts, halo_pts, (int32_t)t_lane_read((uint32_t)e0, team << 4), own_base, lane_bytes);
-    bool first_sorted = false;
-    if (SELECT && steps > 0) {
+    auto entry_for = [&](int it, int32_t reg) -> int32_t {  // `it` wave-uniform, reg = entry_reg(it >> 4)
+      const int32_t e = (int32_t)t_lane_read((uint32_t)reg, (team << 4) + (it & 15));
+      return it < steps ? e : nan_entry;
+    };
+    // A block in flight is ONE 128-bit value (x, y, z, id bits): carried through the loop as a vector, it stays
+    // in the register tuple the load writes.  As four scalars the compiler narrows the COUNT pass's loads
+    // to three words and copies them into other registers at the loop's back edge -- which waits for
+    // every load in flight.
+    auto fetch = [&](int32_t entry) -> t_point4 {
+      const LbvhPoint p = load_block_point<HALO>(own_pts, halo_pts, entry, own_base, lane_bytes);
+      return t_point4{p.x, p.y, p.z, __int_as_float(p.id)};
+    };
+    auto unpack = [](const t_point4 &v) -> LbvhPoint { return LbvhPoint{v.x, v.y, v.z, __float_as_int(v.w)}; };
+    auto sort_first = [&](const LbvhPoint &p) {
       // The first block (the query's own) meets an empty list: every candidate in it would be inserted,
       // one lock-step round each.  Instead the team SORTS its 16 keys (non-candidates = the empty key)
       // with a bitonic network written so that every exchange keeps the smaller key in the lower lane:
       // mirror within 2, 4, 8, 16 lanes followed by xor 4 / 2 / 1 steps -- ten exchanges of two
       // cross-lane moves (DPP quad permutes and mirrors, one ds_swizzle) and a 64-bit compare each.
-      const LbvhPoint &p = pa;
       const float dx = p.x - t_qx, dy = p.y - t_qy, dz = p.z - t_qz;
       const float t = fmaxf(fmaxf(fabsf(dx), fabsf(dy)), fabsf(dz));
       bool in = t <= in_below;
@@ -414,8 +439,8 @@ __device__ __forceinline__ void team_pass(const TeamArgs &a, const TeamLds &L, i
       bi[0] = cand ? (uint32_t)p.id : 0u;
       const bool up1 = (tl & 1) != 0, up2 = (tl & 2) != 0, up4 = (tl & 4) != 0, up8 = (tl & 8) != 0;
       auto exchange = [&](uint32_t pd, uint32_t pi, bool upper) {
-        const uint64_t mine = ((uint64_t)bd[0] << 32) | bi[0], other = ((uint64_t)pd << 32) | pi;
-        const bool take = (other < mine) != upper;  // lower lane: the smaller key; upper lane: the larger (equal: either)
+        const uint64_t mine_k = ((uint64_t)bd[0] << 32) | bi[0], other = ((uint64_t)pd << 32) | pi;
+        const bool take = (other < mine_k) != upper;  // lower lane: the smaller key; upper lane: the larger (equal: either)
         bd[0] = take ? pd : bd[0];
         bi[0] = take ? pi : bi[0];
       };
@@ -430,24 +455,36 @@ __device__ __forceinline__ void team_pass(const TeamArgs &a, const TeamLds &L, i
       exchange(t_dpp<0x4e>(bd[0]), t_dpp<0x4e>(bi[0]), up2);
       exchange(t_dpp<0xb1>(bd[0]), t_dpp<0xb1>(bi[0]), up1);
       tau2 = knn_gate_from_worst(kth_dist());  // k > 16: the second register is still empty, the gate stays open
-      first_sorted = true;
+    };
+    t_point4 b0, b1, b2, b3;
+    {
+      // issued in ring order (the scheduler would reorder four independent loads, and the loop's
+      // s_waitcnt vmcnt(N) is the minimum over the orders it can be entered with)
+      const int32_t s0 = entry_for(0, e0), s1 = entry_for(1, e0), s2 = entry_for(2, e0), s3 = entry_for(3, e0);
+      b0 = fetch(s0);
+      __builtin_amdgcn_sched_barrier(0);
+      b1 = fetch(s1);
+      __builtin_amdgcn_sched_barrier(0);
+      b2 = fetch(s2);
+      __builtin_amdgcn_sched_barrier(0);
+      b3 = fetch(s3);
+      __builtin_amdgcn_sched_barrier(0);
     }
-    for (int base = 0; base < steps; base += 16) {
-      const int j = base >> 4;
-      const int32_t ecur = entry_reg(j), enext = entry_reg(j < 5 ? j + 1 : 5);
-      auto entry_at = [&](int it) -> int32_t {  // base < it <= base + 17, wave-uniform
-        const int c = it - base;
-        return (int32_t)t_lane_read((uint32_t)(c >= 16 ? enext : ecur), (team << 4) + (c & 15));
-      };
-      const int end = min(base + 16, steps);
-      for (int it = base; it < end; it += 2) {
-        const LbvhPoint pb = load_block_point<HALO>(own_pts, halo_pts, entry_at(it + 1), own_base, lane_bytes);
-        if (!(first_sorted && it == 0)) process(pa);
-        if (it + 1 < end) {
-          pa = load_block_point<HALO>(own_pts, halo_pts, entry_at(it + 2), own_base, lane_bytes);
-          process(pb);
-        }
-      }
+    for (int it = 0; it < steps; it += 4) {
+      // addresses of the next group, from the entry register that holds positions it+4 .. it+7
+      const int32_t preg = entry_reg(min((it + 4) >> 4, 5));
+      const int32_t a0 = entry_for(it + 4, preg), a1 = entry_for(it + 5, preg), a2 = entry_for(it + 6, preg), a3 = entry_for(it + 7, preg);
+      if (SELECT && it == 0)
+        sort_first(unpack(b0));
+      else
+        process(unpack(b0));
+      b0 = fetch(a0);
+      if (it + 1 < steps) process(unpack(b1));
+      b1 = fetch(a1);
+      if (it + 2 < steps) process(unpack(b2));
+      b2 = fetch(a2);
+      if (it + 3 < steps) process(unpack(b3));
+      b3 = fetch(a3);
     }
     cnt = t_team_sum(cnt);
     const uint32_t self = cnt ? 1u : 0u;  // a query lies in its own box, and ids are unique
@@ -1263,8 +1300,14 @@ template <bool HALO, int NREG>
 __global__ void __launch_bounds__(kTeamBlock) tie_fix_kernel(TeamArgs a, const int32_t *slots, int32_t nslots) {
   // nslots < 0: `slots` is the kernels' own list (knn_flag_tie), as long as the device-side count says --
   // launched without the host knowing whether anything was flagged; nothing was: every wave leaves at once
-  if (nslots < 0) nslots = (int32_t)min(a.counters[kTieCounter], (unsigned long long)kTieListCap);
-  if (nslots == 0) return;
+  // nslots == -2: `slots` is a compacted list whose length hipCUB's select wrote to a.slot_count.  The host's
+  // count of knn_flag_tie calls is only an upper bound of it (a wave-kernel solve that gives up on its
+  // LDS stack is redone by the lane kernel, which flags the same rows a second time).
+  if (nslots == -2)
+    nslots = *a.slot_count;
+  else if (nslots < 0)
+    nslots = (int32_t)min(a.counters[kTieCounter], (unsigned long long)kTieListCap);
+  if (nslots <= 0) return;
   __shared__ int32_t stack_mem[4 * kFixStack];
   __shared__ WalkLevel levels[2][LBVH_WIDE_LEVELS];
   const int lane = threadIdx.x & 63, team = lane >> 4, tl = lane & 15;
@@ -1281,10 +1324,11 @@ __global__ void __launch_bounds__(kTeamBlock) tie_fix_kernel(TeamArgs a, const i
     if (lane == 0) base = (int)atomicAdd(&a.counters[kTieCounter + 1], 4ull);
     base = __builtin_amdgcn_readfirstlane(base);
     if (base >= nslots) break;
-    const bool active = base + team < nslots;
+    bool active = base + team < nslots;
     const int32_t slot = active ? slots[base + team] : 0;
     const LbvhPoint q = a.bvh.points[slot];
     const int32_t row = a.bvh.prim_id[slot];
+    active = active && a.tie[slot] != 0;  // a listed slot that is not flagged (any more) keeps its row
     const int level = active ? (int)a.tie[slot] - 1 : 0;
     float r = a.start_radius;
     for (int i = 0; i < level; i++) r = r * 2.0f;
@@ -1456,7 +1500,7 @@ __global__ void __launch_bounds__(kTeamBlock) tie_fix_kernel(TeamArgs a, const i
 
 bool Engine::team_kernel_supports(int k) { return k >= 1 && k <= 64; }
 
-void Engine::launch_tie_fix(const SolveArgs &sa, const int32_t *slots, int32_t nslots, int blocks, hipStream_t s) {
+void Engine::launch_tie_fix(const SolveArgs &sa, const int32_t *slots, int32_t nslots, int blocks, hipStream_t s, const int32_t *d_slot_count) {
   TeamArgs a;
   std::memset(&a, 0, sizeof a);
   a.bvh = bvh_.view();
@@ -1470,6 +1514,7 @@ void Engine::launch_tie_fix(const SolveArgs &sa, const int32_t *slots, int32_t n
   a.out_fb = sa.d_fb;
   a.tie = tie_;
   a.tie_list = tie_list_;
+  a.slot_count = d_slot_count;
   a.counters = counters_;
   using FixEntry = void (*)(TeamArgs, const int32_t *, int32_t);
   static const FixEntry entries[2][3] = {{tie_fix_kernel<false, 1>, tie_fix_kernel<false, 2>, tie_fix_kernel<false, 4>},
@@ -1494,7 +1539,9 @@ void Engine::fix_ties(const SolveArgs &sa, tknnSolveInfo *info, hipStream_t s) {
   const int64_t n = bvh_.size();
   hipDeviceProp_t prop;
   OWLMI_HIP(hipGetDeviceProperties(&prop, device_));
-  auto launch = [&](int blocks, const int32_t *slots, int32_t nslots) { launch_tie_fix(sa, slots, nslots, blocks, s); };
+  auto launch = [&](int blocks, const int32_t *slots, int32_t nslots, const int32_t *d_len = nullptr) {
+    launch_tie_fix(sa, slots, nslots, blocks, s, d_len);
+  };
   OWLMI_HIP(hipMemsetAsync(counters_ + kTieCounter + 1, 0, 2 * sizeof(unsigned long long), s));  // work cursor, rows left
   // First go: the kernels' own list, count read on the device -- no host round trip before the launch;
   // the usual handful of rows (or none) costs one small launch behind the solve.
@@ -1529,7 +1576,8 @@ void Engine::fix_ties(const SolveArgs &sa, tknnSolveInfo *info, hipStream_t s) {
     OWLMI_HIP(hipcub::DeviceSelect::Flagged(wave_ws_, tmp_bytes, iota, flags, slot_list_, d_count, (int)n, s));
     OWLMI_HIP(hipMemsetAsync(counters_ + kTieCounter + 1, 0, 2 * sizeof(unsigned long long), s));
     OWLMI_HIP(hipEventRecord(ev_a_, s));
-    launch((int)std::min<int64_t>((flagged + 3) / 4, (int64_t)prop.multiProcessorCount * 16), slot_list_, (int32_t)flagged);
+    // the list's length is read on the device (d_count): `flagged` counts flag calls, an upper bound
+    launch((int)std::min<int64_t>((std::min<int64_t>(flagged, n) + 3) / 4, (int64_t)prop.multiProcessorCount * 16), slot_list_, -2, d_count);
     OWLMI_HIP(hipEventRecord(ev_b_, s));
     OWLMI_HIP(hipMemcpyAsync(h_counters_, counters_ + kTieCounter, 3 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
     OWLMI_HIP(hipStreamSynchronize(s));
@@ -1595,6 +1643,7 @@ bool Engine::solve_team(const SolveArgs &sa, tknnSolveInfo *info, hipStream_t s)
   a.done = done_;
   a.tie = tie_;
   a.tie_list = tie_list_;
+  a.slot_count = nullptr;
   a.isect_sorted = isect_sorted_;
   a.next_level = next_level_;
   a.counters = counters_;

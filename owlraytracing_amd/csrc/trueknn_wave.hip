@@ -446,12 +446,16 @@ void Engine::solve_wave(const SolveArgs &sa, tknnSolveInfo *info, hipStream_t s,
   OWLMI_HIP(hipStreamSynchronize(s));
   float ms = 0;
   OWLMI_HIP(hipEventElapsedTime(&ms, ev_a_, ev_b_));
-  if (h_counters_[5] & 2ull) {
+  if ((h_counters_[5] & 2ull) || wave_force_redo_) {  // (TKNN_WAVE_FORCE_REDO: tests take this path without a pathological tree)
     // LDS node stack exhausted on some packet (pathologically deep tree): redo with the lane kernel
-    if (only_unfinished)
+    if (only_unfinished) {
       continue_lane(sa, 0, info, s);  // done[] still names the stragglers; rows are simply rewritten
-    else
+    } else {
+      // the whole solve is redone: forget the rows this launch has flagged, or they are counted twice
+      OWLMI_HIP(hipMemsetAsync(tie_, 0, (size_t)n, s));
+      OWLMI_HIP(hipMemsetAsync(counters_ + kTieCounter, 0, 3 * sizeof(unsigned long long), s));
       solve_lane(sa, info, s);
+    }
     return;
   }
   if (h_counters_[5] & 1ull) throw RoundsExceeded{};

@@ -47,6 +47,15 @@ def morton63(points, lo, extent):
     return (spread(q[:, 0]) << 2) | (spread(q[:, 1]) << 1) | spread(q[:, 2])
 
 
+def sample_positions(count, samples, device):
+    """`samples` evenly spaced positions in [0, count-1], first and last included, in exact integer
+    arithmetic (a float32 linspace rounds its end point up to `count` once count > 2**24: an
+    out-of-bounds gather on tiles of 50 M points)."""
+    last = max(int(count) - 1, 0)
+    steps = torch.arange(samples, dtype=torch.int64, device=device)
+    return (steps * last) // max(samples - 1, 1)
+
+
 class _Comm:
     """The three collectives the path needs, on device tensors (nccl) or host-staged (gloo)."""
 
@@ -154,7 +163,7 @@ class ShardedTrueKNN:
         codes, points, ids = codes[order], points[order], ids[order]
         # splitters: W-quantiles of the union of per-rank sorted samples
         s = 1024
-        pick = torch.linspace(0, max(len(codes) - 1, 0), s, device=dev).long()
+        pick = sample_positions(len(codes), s, dev)
         sample = codes[pick] if len(codes) else torch.full((s,), 2 ** 62, dtype=torch.int64, device=dev)
         allsamp = comm.all_gather(sample).flatten().sort().values
         cut = torch.tensor([len(allsamp) * (g + 1) // comm.world for g in range(comm.world - 1)], device=dev).long()

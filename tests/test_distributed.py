@@ -37,6 +37,23 @@ def _check(got, name, n, k, r0=None):
     assert int(got["rounds"]) == ref["rounds"]
 
 
+@pytest.mark.parametrize("count", [1, 2, 1023, 1024, 1025, (1 << 24) + 1, 33_554_436, 50_000_000, (1 << 31) + 7])
+def test_splitter_sample_positions_stay_inside_large_tiles(count):
+    """The splitter sample of load_points indexes the rank's sorted codes: positions must be exact
+    integers inside [0, count-1] at any tile size (a float32 linspace returns `count` itself from
+    2**24 points on: 33 554 436 and 50 000 000 are the cases the round-1 review measured)."""
+    import torch
+
+    from owlraytracing_amd.distributed import sample_positions
+    pick = sample_positions(count, 1024, torch.device("cpu"))
+    assert pick.dtype == torch.int64 and len(pick) == 1024
+    assert int(pick[0]) == 0 and int(pick[-1]) == count - 1
+    assert bool((pick[1:] >= pick[:-1]).all()) and int(pick.max()) < count
+    # evenly spaced: neighbouring gaps differ by at most one
+    gaps = pick[1:] - pick[:-1]
+    assert int(gaps.max() - gaps.min()) <= 1
+
+
 @pytest.mark.parametrize("world,name,n,k", [(2, "uniform", 3000, 5), (3, "clustered", 2500, 4), (2, "planar", 2000, 3)])
 def test_tiles_and_halo_exchange_reproduce_the_single_process_result(tmp_path, world, name, n, k):
     """gloo, CPU ranks, checker-backed engine: partition, halo selection, straggler loop, global ids."""
