@@ -49,11 +49,17 @@ namespace {
 constexpr int kTeamBlock = 64;      // one wave per workgroup: LDS, not the block shape, limits residency
 constexpr int kMaxBlocks = 256;     // leaf blocks one packet may need per level (slot fits a byte)
 #ifndef TKNN_MAX_PER_QUERY
-#define TKNN_MAX_PER_QUERY 96
+#define TKNN_MAX_PER_QUERY 72
 #endif
-constexpr int kMaxPerQuery = TKNN_MAX_PER_QUERY;  // leaf blocks one query may need per level
+constexpr int kMaxPerQuery = TKNN_MAX_PER_QUERY;
+#ifndef TKNN_MERGE_AT
+#define TKNN_MERGE_AT 12  // buffered candidates of some team at the end of a group of four blocks that trigger a merge
+#endif
+#ifndef TKNN_TEAM_WAVES
+#define TKNN_TEAM_WAVES 4  // waves per SIMD the packet kernel's register allocation aims at
+#endif  // leaf blocks one query may need per level
 constexpr int kTeamStack = 192;     // wide-pyramid stack entries per wave
-constexpr int kQrecStride = 8;      // floats per LDS query record (layout below)
+constexpr int kQrecStride = 6;      // floats per LDS query record (layout below)
 constexpr int kScanBudget = 16384;  // leaf blocks one packet-level may test against its queries before it is handed over
 constexpr int kMaxStep = 2;          // radius levels one gather may serve (the count slots and the inner-box test assume <= 2)
 // LDS per wave: query records | block list | per-query block lists | counts, query list / stack.
@@ -66,11 +72,22 @@ constexpr int kLdsCnt = 64 * 2 * 4;  // per query: candidates at the inner level
 constexpr int kLdsList = 64 * 4 + 16;  // + the bucket-presence word of the list builder
 constexpr int kLdsStack = kTeamStack * 4;
 constexpr int kLdsShared = (kLdsCnt + kLdsList) > kLdsStack ? (kLdsCnt + kLdsList) : kLdsStack;
-constexpr int kTeamLds = kLdsQrec + kLdsBlk + kLdsMask + kLdsShared;
+// per team: the block entries of the query it serves, resolved and in visit order (+ 4: a pass
+// prefetches one group of four past the end of a list rounded up to whole groups)
+constexpr int kEntStride = kMaxPerQuery + 4;
+constexpr int kLdsEnt = 4 * kEntStride * 4;
+constexpr int kLdsSharedPadded = (kLdsShared + 15) & ~15;  // the entry lists are read 16 bytes at a time
+// per team (k <= 16): candidates that passed the gate since the last merge into the team's sorted list, as
+// 64-bit (dist, index) keys, and how many there are.  At most 16 when a block is tested, so 32 hold any block.
+constexpr int kCandCap = 32;
+constexpr int kLdsCand = 4 * kCandCap * 8 + 16;
+constexpr int kTeamLds = kLdsQrec + kLdsBlk + kLdsMask + kLdsSharedPadded + kLdsEnt + kLdsCand;
+static_assert(kEntStride % 4 == 0 && (kLdsQrec + kLdsBlk + kLdsMask) % 16 == 0, "entry lists must be 16-byte aligned");
 
 // LDS query record: [0..2] q, [3] id, [4] radius of the box the pass works in (outermost level of
-// the step for COUNT, the finishing level for SELECT), [5] margin of the fast box test, [6] row,
-// [7] packed: #blocks | position of the query's own block in its list << 8.
+// the step for COUNT, the finishing level for SELECT), [5] packed: #blocks | position of the query's
+// own block in its list << 8.  (The margin of the fast box test and the query's row are recomputed /
+// re-read by the passes: 512 bytes of LDS decide between 15 and 16 waves per CU.)
 //
 // The candidate test (deviceCode.cu:38-56: fl(c-r) <= q <= fl(c+r) per axis) is done in two tiers.
 // With t = max |fl(c_a - q_a)| over the axes (the differences the distance needs anyway) and the
@@ -163,8 +180,13 @@ template <int CTRL>
 __device__ __forceinline__ uint32_t t_dpp(uint32_t v) {
   return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, true);
 }
-// value of lane (mine ^ 4): ds_swizzle in bit mode (and 0x1f, or 0, xor 4)
-__device__ __forceinline__ uint32_t t_xor4(uint32_t v) { return (uint32_t)__builtin_amdgcn_ds_swizzle((int)v, 0x101f); }
+// value of lane (mine ^ 4): lanes 0-3 and 8-11 of a row read four lanes up, the others four lanes down -- two
+// DPP moves with complementary bank masks (a ds_swizzle does it in one instruction, but through the LDS
+// crossbar: 24 cycles of the LDS pipe and its latency, scripts/microbench/issue_rate.hip)
+__device__ __forceinline__ uint32_t t_xor4(uint32_t v) {
+  const int up = __builtin_amdgcn_update_dpp(0, (int)v, 0x104 /*row_shl:4*/, 0xf, 0x5, false);
+  return (uint32_t)__builtin_amdgcn_update_dpp(up, (int)v, 0x114 /*row_shr:4*/, 0xf, 0xa, false);
+}
 
 // my left neighbour's value inside the team (lane 0 of a team gets 0: bound_ctrl)
 __device__ __forceinline__ uint32_t t_team_shr1(uint32_t v) {
@@ -190,13 +212,13 @@ __device__ __forceinline__ uint32_t t_count_keep(uint32_t acc, unsigned long lon
 
 // squared distance from the three differences: knn_dist2's expression ((x*x) + (y*y)) + (z*z),
 // x and y squared in one packed instruction
-typedef float t_float2 __attribute__((ext_vector_type(2)));
 typedef float t_point4 __attribute__((ext_vector_type(4)));
+// knn_dist2's expression ((x*x) + (y*y)) + (z*z), every operation rounded on its own.  Plain instructions: a
+// packed v_pk_mul_f32 issues in 6.3 cycles against 2.4 for each of the two multiplies it replaces
+// (scripts/microbench/issue_rate.hip); the file is compiled with -fno-slp-vectorize for the same reason.
 __device__ __forceinline__ float t_dist2(float dx, float dy, float dz) {
 #pragma clang fp contract(off)
-  const t_float2 dxy = {dx, dy};
-  const t_float2 sq = dxy * dxy;
-  return (sq.x + sq.y) + (dz * dz);
+  return ((dx * dx) + (dy * dy)) + (dz * dz);
 }
 
 // one leaf block = LBVH_BLOCK sorted points, 16 bytes each; lane tl of a team reads point tl.
@@ -223,6 +245,9 @@ struct TeamLds {
   uint8_t *qblk;      // [64][kMaxPerQuery] per-query slots into blk[]
   uint32_t *qcnt;     // [64][2] out: candidates in the inner box, in the outer box | self << 31
   int32_t *qlist;     // compact list of the queries this pass serves
+  int32_t *ent;       // [4][kEntStride] per team: resolved block entries of its query, in visit order
+  unsigned long long *cand;  // [4][kCandCap] per team: keys waiting to be merged into its list
+  uint32_t *cand_n;          // [4] how many
 };
 
 // Can two candidates of one query at the same fp32 distance d have become candidates in DIFFERENT
@@ -246,24 +271,38 @@ __device__ __forceinline__ bool tie_may_straddle(float d, float r0, float r_last
 // (deviceCode.cu:74,103).  SELECT = true: also keep the k best (dist,index) keys, lane j of the
 // team holding the j-th, and write the row if the query turns out finished (>= k others).
 // NREG: list registers per lane -- the team's sorted list holds 16 * NREG keys (k <= 16: 1, k <= 32: 2, k <= 64: 4)
-template <bool SELECT, bool HALO, int NREG, bool FULL>
-__device__ __forceinline__ void team_pass(const TeamArgs &a, const TeamLds &L, int n_list, float r_inner, int m,
+// TWO: a COUNT pass that also counts the inner box of a two-level step (a template flag: as a run-time value the
+// compiler kept "m > 1" as a lane mask and re-derived a branch from it for every block)
+template <bool SELECT, bool HALO, int NREG, bool FULL, bool TWO>
+__device__ __forceinline__ void team_pass(const TeamArgs &a, const TeamLds &L, int n_list, float r_inner, int32_t first_slot,
                                           const LbvhPoint *own_pts, const LbvhPoint *halo_pts, int lane) {
   const int team = lane >> 4, tl = lane & 15;
-  m = __builtin_amdgcn_readfirstlane(m);  // wave-uniform by construction; says so to the compiler (scalar branches on it)
-  n_list = __builtin_amdgcn_readfirstlane(n_list);
+  static_assert(!(SELECT && TWO), "only a COUNT pass serves two levels");
+  n_list = __builtin_amdgcn_readfirstlane(n_list);  // wave-uniform by construction; says so to the compiler (scalar branches on it)
+  [[maybe_unused]] unsigned long long tp[4] = {0, 0, 0, 0};  // TKNN_DIAG_BUILD, flag 128: setup | first group | other groups | epilogue
   for (int r0 = 0; r0 < n_list; r0 += 4) {
+    [[maybe_unused]] unsigned long long tp_mark = 0;
+    if (TKNN_DIAG_BUILD && (a.diag & 128)) tp_mark = __builtin_amdgcn_s_memtime();
+#define TP_LAP(i)                                                     \
+  do {                                                                \
+    if (TKNN_DIAG_BUILD && (a.diag & 128)) {                          \
+      const unsigned long long now_ = __builtin_amdgcn_s_memtime();   \
+      tp[i] += now_ - tp_mark;                                        \
+      tp_mark = now_;                                                 \
+    }                                                                 \
+  } while (0)
     const bool on = r0 + team < n_list;
     int qi = 0;
     if (on) qi = L.qlist[r0 + team];
     const float *rec = L.qrec + qi * kQrecStride;
     const float t_qx = rec[0], t_qy = rec[1], t_qz = rec[2];
     const int32_t t_qid = __float_as_int(rec[3]);
-    const float t_r = rec[4], t_mg = rec[5];
+    const float t_r = rec[4];
+    const float t_mg = (fmaxf(fmaxf(fabsf(t_qx), fabsf(t_qy)), fabsf(t_qz)) + 2.0f * t_r) * 4.76837158203125e-07f;  // 2^-21, see above
     const float in_below = t_r - t_mg, in_upto = t_r + t_mg;          // certainly / possibly a candidate
     const float i0_below = r_inner - t_mg, i0_upto = r_inner + t_mg;  // same for the inner level of a two-level COUNT step
     uint32_t cnt_i0 = 0;  // inner level of a two-level COUNT step (m = levels served by this gather, wave-uniform)
-    const int packed = __float_as_int(rec[7]);
+    const int packed = __float_as_int(rec[5]);
     const int my_n = on ? (packed & 0xff) : 0;  // leaf blocks of my team's query
     // wave-uniform trip count: longest list of the 4 teams -- from v_readlane values only, so that the
     // compiler keeps it (and the loop tests below) in scalar registers
@@ -280,12 +319,10 @@ __device__ __forceinline__ void team_pass(const TeamArgs &a, const TeamLds &L, i
     // my list" check
     const int32_t nan_block = a.wide[0].count[0];
     const int32_t nan_entry = resolve_entry<HALO>(nan_block);
-    int32_t e0 = nan_entry, e1 = nan_entry, e2 = nan_entry, e3 = nan_entry, e4 = nan_entry, e5 = nan_entry;  // named, not an array: must stay in VGPRs
     // SELECT visits blocks outward from the query's own block, alternating sides of its Morton-ordered
     // list: near blocks first tightens the k-th-distance gate early (about 30 % fewer inserts than
     // list order on uniform data) and changes nothing else -- the result does not depend on order.
-    // COUNT takes the list as it is.  Branch-free: registers are filled by whole-wave decisions
-    // (`steps`), lanes past their list's end read some byte of their row and drop it.
+    // COUNT takes the list as it is.
     const int own_pos = (packed >> 8) & 0xff;
     const int both = min(own_pos, last - own_pos);
     const bool right_longer = last - own_pos > own_pos;
@@ -303,15 +340,16 @@ __device__ __forceinline__ void team_pass(const TeamArgs &a, const TeamLds &L, i
       if (TKNN_DIAG_BUILD && (a.diag & 64)) e = L.blk[mine[0]];  // every visit reads one and the same block: what do cache misses cost?
       return resolve_entry<HALO>(pos <= last ? e : nan_block);
     };
-    e0 = list_entry(tl);
-    if (steps > 16) e1 = list_entry(tl + 16);
-    if (steps > 32) e2 = list_entry(tl + 32);
-    if (steps > 48) e3 = list_entry(tl + 48);
-    if (steps > 64) e4 = list_entry(tl + 64);
-    if (steps > 80) e5 = list_entry(tl + 80);
-    auto entry_reg = [&](int j) -> int32_t {  // j is wave-uniform
-      return j == 0 ? e0 : (j == 1 ? e1 : (j == 2 ? e2 : (j == 3 ? e3 : (j == 4 ? e4 : e5))));
-    };
+    // The team's entries go to LDS once, resolved (byte offsets) and in visit order, lane tl writing
+    // positions tl, tl + 16, ...; the loop below then fetches four of them with ONE 16-byte LDS read per
+    // team (same address in the team's 16 lanes) -- no cross-lane read, no select, no address
+    // arithmetic per block.  Positions up to the longest list rounded up to whole groups of four, plus
+    // one group of prefetch, name the all-NaN block.
+    const int steps4 = (steps + 3) & ~3;
+    int32_t *my_ent = L.ent + team * kEntStride;
+    for (int base = 0; base < steps4 + 4; base += 16)
+      if (base + tl < kEntStride) my_ent[base + tl] = list_entry(base + tl);
+    t_wave_sync();
     uint32_t cnt = 0;
     uint32_t bd[NREG], bi[NREG];  // register j of lane t holds list entry 16 j + t (indices are compile-time: stays in VGPRs)
 #pragma unroll
@@ -333,34 +371,116 @@ __device__ __forceinline__ void team_pass(const TeamArgs &a, const TeamLds &L, i
       return __uint_as_float(t_lane_read(reg, (team << 4) + ((a.k - 1) & 15)));
     };
     float tau2 = INFINITY;
-    // one block's test; `it` is wave-uniform
-    // Lane predicates are kept as 64-bit wave masks (SGPR pairs) from the compare to the branch: a
-    // bool that crosses a branch would be turned into a VGPR 0/1 and back, two VALU instructions each.
+    // ---- sorting network pieces (k <= 16: the list is one register pair, lane j holds entry j) ----------
+    const bool up1 = (tl & 1) != 0, up2 = (tl & 2) != 0, up4 = (tl & 4) != 0, up8 = (tl & 8) != 0;
+    // one compare-exchange with the lane whose key is (pd, pi): the lower lane keeps the smaller key
+    auto exchange = [&](uint32_t &kd, uint32_t &ki, uint32_t pd, uint32_t pi, bool upper) {
+      const uint64_t mine_k = ((uint64_t)kd << 32) | ki, other = ((uint64_t)pd << 32) | pi;
+      const bool take = (other < mine_k) != upper;  // lower lane: the smaller key; upper lane: the larger (equal: either)
+      kd = take ? pd : kd;
+      ki = take ? pi : ki;
+    };
+    // 16 keys of a team, one per lane, into ascending order: a bitonic network written so that every exchange
+    // keeps the smaller key in the lower lane -- mirror within 2, 4, 8, 16 lanes followed by xor 4 / 2 / 1
+    // steps; ten exchanges of DPP moves (quad permutes, mirrors, row shifts) and a 64-bit compare each.
+    auto sort16 = [&](uint32_t &kd, uint32_t &ki) {
+      exchange(kd, ki, t_dpp<0xb1>(kd), t_dpp<0xb1>(ki), up1);    // pairs
+      exchange(kd, ki, t_dpp<0x1b>(kd), t_dpp<0x1b>(ki), up2);    // mirror within 4
+      exchange(kd, ki, t_dpp<0xb1>(kd), t_dpp<0xb1>(ki), up1);
+      exchange(kd, ki, t_dpp<0x141>(kd), t_dpp<0x141>(ki), up4);  // mirror within 8 (row_half_mirror)
+      exchange(kd, ki, t_dpp<0x4e>(kd), t_dpp<0x4e>(ki), up2);    // xor 2
+      exchange(kd, ki, t_dpp<0xb1>(kd), t_dpp<0xb1>(ki), up1);
+      exchange(kd, ki, t_dpp<0x140>(kd), t_dpp<0x140>(ki), up8);  // mirror within 16 (row_mirror)
+      exchange(kd, ki, t_xor4(kd), t_xor4(ki), up4);
+      exchange(kd, ki, t_dpp<0x4e>(kd), t_dpp<0x4e>(ki), up2);
+      exchange(kd, ki, t_dpp<0xb1>(kd), t_dpp<0xb1>(ki), up1);
+    };
+    // k <= 16: candidates that pass the gate are not inserted one lock-step round each (7.4 rounds of some
+    // 25 vector instructions per query on the benchmark, two LDS-crossbar reads each: a third of the
+    // kernel's vector work for 11.6 candidates per query).  They go to the team's LDS buffer -- a slot from
+    // an LDS counter, no cross-lane traffic -- and are MERGED into the sorted list sixteen at a time: sort
+    // the sixteen (network above), meet the list mirrored (lane j against sorted key 15 - j: the sixteen
+    // smallest of both survive, as a bitonic sequence), four half-cleaners.  Some 80 vector instructions
+    // whatever the number of candidates, no LDS crossbar, no scalar mask arithmetic.  Between merges the
+    // gate is the last merge's k-th distance: looser than it could be, never wrong.
+    bool dirty = false;  // wave-uniform: some team has buffered candidates
+    auto merge_buffer = [&]() {
+      t_wave_sync();
+      const uint32_t fill = L.cand_n[team];
+#pragma unroll
+      for (int row = 0; row < kCandCap / 16; row++) {
+        if (row > 0 && __ballot(fill > 16u * (uint32_t)row) == 0ull) break;
+        const uint32_t at = 16u * (uint32_t)row + (uint32_t)tl;
+        const unsigned long long key = at < fill ? L.cand[team * kCandCap + at] : KNN_EMPTY_KEY;
+        uint32_t kd = (uint32_t)(key >> 32), ki = (uint32_t)key;
+        sort16(kd, ki);
+        const uint32_t od = t_dpp<0x140>(kd), oi = t_dpp<0x140>(ki);  // sorted key 15 - tl
+        const uint64_t mine_k = ((uint64_t)bd[0] << 32) | bi[0], other = ((uint64_t)od << 32) | oi;
+        const bool take = other < mine_k;
+        if (full) left_out = min(left_out, take ? bd[0] : od);  // the key of the pair that finds no room (team minimum taken at the end)
+        bd[0] = take ? od : bd[0];
+        bi[0] = take ? oi : bi[0];
+        exchange(bd[0], bi[0], t_dpp<0x128>(bd[0]), t_dpp<0x128>(bi[0]), up8);  // xor 8 (row_ror:8)
+        exchange(bd[0], bi[0], t_xor4(bd[0]), t_xor4(bi[0]), up4);
+        exchange(bd[0], bi[0], t_dpp<0x4e>(bd[0]), t_dpp<0x4e>(bi[0]), up2);
+        exchange(bd[0], bi[0], t_dpp<0xb1>(bd[0]), t_dpp<0xb1>(bi[0]), up1);
+      }
+      t_wave_sync();
+      if (tl == 0) L.cand_n[team] = 0u;
+      t_wave_sync();
+      dirty = false;
+      tau2 = knn_gate_from_worst(kth_dist());
+    };
+    // one block's test.  The candidate test in two tiers (see the record layout above): outside the
+    // band |t - r| <= M the comparison t <= r IS the literal test; inside it (about 1e-6 of the points,
+    // every point of a face-aligned lattice) the literal test runs.  The band check is one subtraction,
+    // one compare and a branch that is almost never taken -- lane predicates cost a compare (twice a
+    // plain VALU instruction on gfx950) and every wave-mask operation a slot of the CU's one scalar
+    // pipe, which this kernel fills as much as the vector pipes (scripts/microbench/issue_rate.hip).
+    auto in_box = [&](const LbvhPoint &p, float t, float radius, float below, float upto) -> unsigned long long {
+      unsigned long long in_m = __ballot(t <= radius);
+      if (__builtin_expect(__ballot(fabsf(t - radius) <= t_mg) != 0ull, 0))
+        in_m = __ballot(t <= below) | (__ballot(t <= upto) & __ballot(knn_in_box(p.x, p.y, p.z, radius, t_qx, t_qy, t_qz)));
+      return in_m;
+    };
     auto process = [&](const LbvhPoint &p) {
       const float dx = p.x - t_qx, dy = p.y - t_qy, dz = p.z - t_qz;
       // NaN only if all three are (sentinels; lbvh.hip turns a point with any NaN coordinate into one)
       const float t = fmaxf(fmaxf(fabsf(dx), fabsf(dy)), fabsf(dz));
-      unsigned long long in_m = __ballot(t <= in_below);
-      const unsigned long long maybe_m = __ballot(t <= in_upto) & ~in_m;
-      if (maybe_m) in_m |= maybe_m & __ballot(knn_in_box(p.x, p.y, p.z, t_r, t_qx, t_qy, t_qz));
+      const unsigned long long in_m = in_box(p, t, t_r, in_below, in_upto);
       cnt = t_count_keep(cnt, in_m, p.id);
-      if (!SELECT && m > 1) {
-        unsigned long long in0_m = __ballot(t <= i0_below);
-        const unsigned long long maybe0_m = __ballot(t <= i0_upto) & ~in0_m;
-        if (maybe0_m) in0_m |= maybe0_m & __ballot(knn_in_box(p.x, p.y, p.z, r_inner, t_qx, t_qy, t_qz));
-        cnt_i0 = t_count(cnt_i0, in0_m);
-      }
+      if (TWO) cnt_i0 = t_count(cnt_i0, in_box(p, t, r_inner, i0_below, i0_upto));
       if (SELECT) {
         const float d2 = t_dist2(dx, dy, dz);
         // candidates that pass the gate.  The query itself sits in its own block, which SELECT visits
         // first and settles in the sorted first step, so no block seen here can hold it (ids are unique).
         unsigned long long pm = in_m & __ballot(d2 <= tau2);
         if (TKNN_DIAG_BUILD && (a.diag & 1)) pm = 0;
-        if (pm) {
+        if (NREG == 1) {
+          if (pm) {
+            if (TKNN_DIAG_BUILD && (a.diag & 16) && lane == 0) atomicAdd(&a.counters[26], (unsigned long long)__popcll(pm));
+            // my candidate's exact key into the team's buffer; a full row of sixteen is merged at once (a block
+            // adds at most sixteen to at most fifteen: the buffer holds 32)
+            bool row_full = false;
+            if ((pm >> lane) & 1ull) {
+              const unsigned long long key = ((unsigned long long)__float_as_uint(knn_sqrt(d2)) << 32) | (uint32_t)p.id;
+              const uint32_t slot = __hip_atomic_fetch_add(&L.cand_n[team], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+              L.cand[team * kCandCap + slot] = key;
+              row_full = slot >= 15u;
+            }
+            dirty = true;
+            if (__ballot(row_full) != 0ull) {
+              if (TKNN_DIAG_BUILD && (a.diag & 16) && lane == 0) atomicAdd(&a.counters[27], 1ull);
+              merge_buffer();
+            }
+          }
+        } else if (pm) {
           // exact key of my candidate, then one team-parallel sorted insert per pending lane
           const uint32_t key_d = __float_as_uint(knn_sqrt(d2));
           const uint32_t key_i = (uint32_t)p.id;
+          if (TKNN_DIAG_BUILD && (a.diag & 16) && lane == 0) atomicAdd(&a.counters[26], (unsigned long long)__popcll(pm));
           do {
+            if (TKNN_DIAG_BUILD && (a.diag & 16) && lane == 0) atomicAdd(&a.counters[27], 1ull);
             const uint32_t pending_mine = (uint32_t)(pm >> (team * 16)) & 0xffffu;  // pending lanes of my team
             const bool has = pending_mine != 0u;
             const int src = (team << 4) + (has ? __ffs((int)pending_mine) - 1 : 0);
@@ -400,18 +520,14 @@ __device__ __forceinline__ void team_pass(const TeamArgs &a, const TeamLds &L, i
         }
       }
     };
-    // A ring of four block buffers: while one block is tested the next three are in flight (a leaf block
-    // comes from the XCD's L2 most of the time: several hundred cycles, against some fifty of work per
-    // block), and the cross-lane reads that fetch the NEXT group's addresses are issued a whole group
-    // ahead, so neither the LDS crossbar nor the cache is waited for in the loop.  Loads are
-    // unconditional and consumed in strict rotation (the compiler's s_waitcnt vmcnt(N) then counts
-    // exactly); visit positions past the longest list of the four teams name the all-NaN block.
+    // A ring of four block buffers: while one block is tested the next three are in flight, and the
+    // NEXT group's four entries are read from LDS a whole group ahead.  Loads are unconditional and
+    // consumed in strict rotation (the compiler's s_waitcnt vmcnt(N) then counts exactly); whole groups
+    // only: positions past a list's end are the all-NaN block, whose points fail every test.
     const LbvhPoint *own_base = a.bvh.points;  // wave-uniform
     const uint32_t lane_bytes = (uint32_t)tl * (uint32_t)sizeof(LbvhPoint);
-    auto entry_for = [&](int it, int32_t reg) -> int32_t {  // `it` wave-uniform, reg = entry_reg(it >> 4)
-      const int32_t e = (int32_t)t_lane_read((uint32_t)reg, (team << 4) + (it & 15));
-      return it < steps ? e : nan_entry;
-    };
+    typedef int32_t t_int4 __attribute__((ext_vector_type(4)));
+    const t_int4 *my_groups = (const t_int4 *)my_ent;
     // A block in flight is ONE 128-bit value (x, y, z, id bits): carried through the loop as a vector, it stays
     // in the register tuple the load writes.  As four scalars the compiler narrows the COUNT pass's loads
     // to three words and copies them into other registers at the loop's back edge -- which waits for
@@ -429,67 +545,69 @@ __device__ __forceinline__ void team_pass(const TeamArgs &a, const TeamLds &L, i
       // cross-lane moves (DPP quad permutes and mirrors, one ds_swizzle) and a 64-bit compare each.
       const float dx = p.x - t_qx, dy = p.y - t_qy, dz = p.z - t_qz;
       const float t = fmaxf(fmaxf(fabsf(dx), fabsf(dy)), fabsf(dz));
-      bool in = t <= in_below;
-      const bool maybe = !in && (t <= in_upto);
-      if (__ballot(maybe)) in = in || (maybe && knn_in_box(p.x, p.y, p.z, t_r, t_qx, t_qy, t_qz));
+      bool in = t <= t_r;
+      if (__ballot(fabsf(t - t_r) <= t_mg) != 0ull) in = (t <= in_below) || ((t <= in_upto) && knn_in_box(p.x, p.y, p.z, t_r, t_qx, t_qy, t_qz));
       cnt = t_count(cnt, __ballot(in));
       bool cand = in && (p.id != t_qid);
       if (TKNN_DIAG_BUILD && (a.diag & 1)) cand = false;
       bd[0] = cand ? __float_as_uint(knn_sqrt(t_dist2(dx, dy, dz))) : 0x7f7fffffu;
       bi[0] = cand ? (uint32_t)p.id : 0u;
-      const bool up1 = (tl & 1) != 0, up2 = (tl & 2) != 0, up4 = (tl & 4) != 0, up8 = (tl & 8) != 0;
-      auto exchange = [&](uint32_t pd, uint32_t pi, bool upper) {
-        const uint64_t mine_k = ((uint64_t)bd[0] << 32) | bi[0], other = ((uint64_t)pd << 32) | pi;
-        const bool take = (other < mine_k) != upper;  // lower lane: the smaller key; upper lane: the larger (equal: either)
-        bd[0] = take ? pd : bd[0];
-        bi[0] = take ? pi : bi[0];
-      };
-      exchange(t_dpp<0xb1>(bd[0]), t_dpp<0xb1>(bi[0]), up1);    // pairs
-      exchange(t_dpp<0x1b>(bd[0]), t_dpp<0x1b>(bi[0]), up2);    // mirror within 4
-      exchange(t_dpp<0xb1>(bd[0]), t_dpp<0xb1>(bi[0]), up1);
-      exchange(t_dpp<0x141>(bd[0]), t_dpp<0x141>(bi[0]), up4);  // mirror within 8 (row_half_mirror)
-      exchange(t_dpp<0x4e>(bd[0]), t_dpp<0x4e>(bi[0]), up2);    // xor 2
-      exchange(t_dpp<0xb1>(bd[0]), t_dpp<0xb1>(bi[0]), up1);
-      exchange(t_dpp<0x140>(bd[0]), t_dpp<0x140>(bi[0]), up8);  // mirror within 16 (row_mirror)
-      exchange(t_xor4(bd[0]), t_xor4(bi[0]), up4);
-      exchange(t_dpp<0x4e>(bd[0]), t_dpp<0x4e>(bi[0]), up2);
-      exchange(t_dpp<0xb1>(bd[0]), t_dpp<0xb1>(bi[0]), up1);
+      sort16(bd[0], bi[0]);
       tau2 = knn_gate_from_worst(kth_dist());  // k > 16: the second register is still empty, the gate stays open
     };
+    TP_LAP(0);
     t_point4 b0, b1, b2, b3;
     {
       // issued in ring order (the scheduler would reorder four independent loads, and the loop's
       // s_waitcnt vmcnt(N) is the minimum over the orders it can be entered with)
-      const int32_t s0 = entry_for(0, e0), s1 = entry_for(1, e0), s2 = entry_for(2, e0), s3 = entry_for(3, e0);
-      b0 = fetch(s0);
+      const t_int4 g = my_groups[0];
+      b0 = fetch(g.x);
       __builtin_amdgcn_sched_barrier(0);
-      b1 = fetch(s1);
+      b1 = fetch(g.y);
       __builtin_amdgcn_sched_barrier(0);
-      b2 = fetch(s2);
+      b2 = fetch(g.z);
       __builtin_amdgcn_sched_barrier(0);
-      b3 = fetch(s3);
+      b3 = fetch(g.w);
       __builtin_amdgcn_sched_barrier(0);
     }
     for (int it = 0; it < steps; it += 4) {
-      // addresses of the next group, from the entry register that holds positions it+4 .. it+7
-      const int32_t preg = entry_reg(min((it + 4) >> 4, 5));
-      const int32_t a0 = entry_for(it + 4, preg), a1 = entry_for(it + 5, preg), a2 = entry_for(it + 6, preg), a3 = entry_for(it + 7, preg);
+      const t_int4 g = my_groups[(it >> 2) + 1];  // entries it+4 .. it+7
       if (SELECT && it == 0)
         sort_first(unpack(b0));
       else
         process(unpack(b0));
-      b0 = fetch(a0);
-      if (it + 1 < steps) process(unpack(b1));
-      b1 = fetch(a1);
-      if (it + 2 < steps) process(unpack(b2));
-      b2 = fetch(a2);
-      if (it + 3 < steps) process(unpack(b3));
-      b3 = fetch(a3);
+      b0 = fetch(g.x);
+      process(unpack(b1));
+      b1 = fetch(g.y);
+      process(unpack(b2));
+      b2 = fetch(g.z);
+      process(unpack(b3));
+      b3 = fetch(g.w);
+      // a tighter gate for the next group as soon as a handful of candidates wait (the first groups, whose
+      // blocks lie next to the query, bring most of them)
+      if (SELECT && NREG == 1 && dirty && __ballot(L.cand_n[team] >= (uint32_t)TKNN_MERGE_AT) != 0ull) {
+        if (TKNN_DIAG_BUILD && (a.diag & 16) && lane == 0) atomicAdd(&a.counters[27], 1ull);
+        merge_buffer();
+      }
+      TP_LAP(it == 0 ? 1 : 2);
+    }
+    if (SELECT && NREG == 1 && dirty) {
+      if (TKNN_DIAG_BUILD && (a.diag & 16) && lane == 0) atomicAdd(&a.counters[27], 1ull);
+      merge_buffer();
+    }
+    if (SELECT && NREG == 1 && full) {
+      // the smallest key left out by any merge, where the tie test below looks for it: lane 15
+      uint32_t v = left_out;
+      v = min(v, (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)v, 0x128 /*row_ror:8*/, 0xf, 0xf, false));
+      v = min(v, (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)v, 0x124 /*row_ror:4*/, 0xf, 0xf, false));
+      v = min(v, (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)v, 0x122 /*row_ror:2*/, 0xf, 0xf, false));
+      v = min(v, (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)v, 0x121 /*row_ror:1*/, 0xf, 0xf, false));
+      left_out = v;
     }
     cnt = t_team_sum(cnt);
     const uint32_t self = cnt ? 1u : 0u;  // a query lies in its own box, and ids are unique
     const uint32_t others = cnt - self;
-    if (!SELECT && m > 1) cnt_i0 = t_team_sum(cnt_i0);
+    if (TWO) cnt_i0 = t_team_sum(cnt_i0);
     uint32_t tied = 0u;
     if (SELECT) {
       // entry j against entry j - 1, for j = 1..k (KList::has_ties is the per-lane form of this)
@@ -514,7 +632,7 @@ __device__ __forceinline__ void team_pass(const TeamArgs &a, const TeamLds &L, i
     if (on && tl == 0) {
       // counts innermost level first; a one-level pass fills slot 0
       uint32_t *out = L.qcnt + qi * 2;
-      if (SELECT || m == 1) {
+      if (!TWO) {
         out[0] = cnt;
         out[1] = (self << 31) | (tied << 30);
       } else {
@@ -526,7 +644,7 @@ __device__ __forceinline__ void team_pass(const TeamArgs &a, const TeamLds &L, i
       // finished at this level (deviceCode.cu:118: k insertions happened): lane j < k stores neighbour j.
       // The query's own lane adds the intersection count and the level afterwards (team_kernel).
       if (on && others >= (uint32_t)a.k) {
-        const int32_t out_row = __float_as_int(rec[6]);
+        const int32_t out_row = a.bvh.prim_id[first_slot + qi];
 #pragma unroll
         for (int reg = 0; reg < NREG; reg++) {
           const int j = tl + 16 * reg;  // my entry of this register
@@ -546,11 +664,15 @@ __device__ __forceinline__ void team_pass(const TeamArgs &a, const TeamLds &L, i
         }
       }
     }
+    TP_LAP(3);
   }
+#undef TP_LAP
+  if (TKNN_DIAG_BUILD && (a.diag & 128) && lane == 0)
+    for (int i = 0; i < 4; i++) atomicAdd(&a.counters[(SELECT ? 36 : 28) + i], tp[i]);  // (32..34: the tie pass)
 }
 
 template <bool HALO, int NREG, bool FULL>
-__global__ void __launch_bounds__(kTeamBlock) __attribute__((amdgpu_waves_per_eu(4))) team_kernel(TeamArgs a) {
+__global__ void __launch_bounds__(kTeamBlock) __attribute__((amdgpu_waves_per_eu(TKNN_TEAM_WAVES))) team_kernel(TeamArgs a) {
   extern __shared__ __align__(16) unsigned char smem[];
   const int lane = threadIdx.x & 63;
   const int wid = threadIdx.x >> 6;  // 0 with one wave per workgroup
@@ -562,6 +684,10 @@ __global__ void __launch_bounds__(kTeamBlock) __attribute__((amdgpu_waves_per_eu
   uint32_t *qcnt = (uint32_t *)(base + kLdsQrec + kLdsBlk + kLdsMask);
   int32_t *qlist = (int32_t *)(base + kLdsQrec + kLdsBlk + kLdsMask + kLdsCnt);
   int32_t *stack = (int32_t *)(base + kLdsQrec + kLdsBlk + kLdsMask);  // shares the counts / query list region
+  int32_t *ent = (int32_t *)(base + kLdsQrec + kLdsBlk + kLdsMask + kLdsSharedPadded);
+  unsigned long long *cand = (unsigned long long *)(base + kLdsQrec + kLdsBlk + kLdsMask + kLdsSharedPadded + kLdsEnt);
+  uint32_t *cand_n = (uint32_t *)(base + kLdsQrec + kLdsBlk + kLdsMask + kLdsSharedPadded + kLdsEnt + 4 * kCandCap * 8);
+  if (lane < 4) cand_n[lane] = 0u;
 
   const LbvhPoint *own_pts = a.bvh.points + tl, *halo_pts = a.halo.points ? a.halo.points + tl : a.bvh.points + tl;
   unsigned long long my_isect_sum = 0, my_levels = 0, my_unfinished = 0, wave_node_tests = 0, wave_point_tests = 0;
@@ -623,6 +749,9 @@ __global__ void __launch_bounds__(kTeamBlock) __attribute__((amdgpu_waves_per_eu
     L.qblk = qblk;
     L.qcnt = qcnt;
     L.qlist = qlist;
+    L.ent = ent;
+    L.cand = cand;
+    L.cand_n = cand_n;
 
     for (;;) {  // radius levels
       PHASE_END(4);
@@ -656,8 +785,6 @@ __global__ void __launch_bounds__(kTeamBlock) __attribute__((amdgpu_waves_per_eu
         rec[2] = q.z;
         rec[3] = __int_as_float(q.id);
         rec[4] = r_out;
-        rec[5] = mg;
-        rec[6] = __int_as_float(row);
       }
       // The pyramid is culled against FOUR boxes, one per 16 Morton-consecutive queries (= one leaf
       // block of queries), not against the packet's one union box: where the Z-curve jumps, or
@@ -835,7 +962,7 @@ __global__ void __launch_bounds__(kTeamBlock) __attribute__((amdgpu_waves_per_eu
       }
       if (TKNN_DIAG_BUILD && (a.diag & 32)) diag_listed += nb;
       const int my_packed = my_nblk | (my_own_pos << 8);  // read back by the teams
-      qrec[lane * kQrecStride + 7] = __int_as_float(my_packed);
+      qrec[lane * kQrecStride + 5] = __int_as_float(my_packed);
 
       PHASE_END(1);
       // ---- 4. passes ---------------------------------------------------------------------------
@@ -872,7 +999,12 @@ __global__ void __launch_bounds__(kTeamBlock) __attribute__((amdgpu_waves_per_eu
       };
       {
         const int n_count = build_qlist(count_first);
-        if (!(TKNN_DIAG_BUILD && (a.diag & 4))) team_pass<false, HALO, NREG, false>(a, L, n_count, r_in0, m, own_pts, halo_pts, lane);
+        if (!(TKNN_DIAG_BUILD && (a.diag & 4))) {
+          if (m > 1)
+            team_pass<false, HALO, NREG, false, true>(a, L, n_count, r_in0, g * 64, own_pts, halo_pts, lane);
+          else
+            team_pass<false, HALO, NREG, false, false>(a, L, n_count, r_in0, g * 64, own_pts, halo_pts, lane);
+        }
         t_wave_sync();
       }
       PHASE_END(2);
@@ -894,7 +1026,7 @@ __global__ void __launch_bounds__(kTeamBlock) __attribute__((amdgpu_waves_per_eu
       {
         t_wave_sync();
         const int n_select = build_qlist(select_now);
-        if (!(TKNN_DIAG_BUILD && (a.diag & 2))) team_pass<true, HALO, NREG, FULL>(a, L, n_select, r_in0, 1, own_pts, halo_pts, lane);
+        if (!(TKNN_DIAG_BUILD && (a.diag & 2))) team_pass<true, HALO, NREG, FULL, false>(a, L, n_select, r_in0, g * 64, own_pts, halo_pts, lane);
         t_wave_sync();
       }
       PHASE_END(3);
@@ -1719,6 +1851,8 @@ bool Engine::solve_team(const SolveArgs &sa, tknnSolveInfo *info, hipStream_t s)
   const TeamEntry entry = entries[with_halo ? 1 : 0][nreg_at][full_list ? 1 : 0];
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)entry, kTeamBlock, lds) != hipSuccess) per_cu = 2;
   per_cu = std::max(1, per_cu);
+  if (const char *cap = getenv("TKNN_TEAM_WAVES_PER_CU"))  // measurements only: how the packet kernel's time scales with the waves in flight
+    per_cu = std::max(1, std::min(per_cu, atoi(cap)));
   const int64_t want = (a.ngroups + kTeamBlock / 64 - 1) / (kTeamBlock / 64);
   const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>(want, (int64_t)prop.multiProcessorCount * per_cu));
 
@@ -1756,6 +1890,22 @@ bool Engine::solve_team(const SolveArgs &sa, tknnSolveInfo *info, hipStream_t s)
     OWLMI_HIP(hipMemcpy(&wave_steps, counters_ + 15, sizeof wave_steps, hipMemcpyDeviceToHost));
     fprintf(stderr, "[team diag] block steps: %.3g wave steps x 4 teams for %.3g listed blocks (lockstep efficiency %.1f%%)\n",
             (double)wave_steps, (double)h_counters_[3] / LBVH_BLOCK, 100.0 * ((double)h_counters_[3] / LBVH_BLOCK) / (4.0 * (double)wave_steps));
+    if (a.diag & 16) {
+      unsigned long long g[2];
+      OWLMI_HIP(hipMemcpy(g, counters_ + 26, sizeof g, hipMemcpyDeviceToHost));
+      fprintf(stderr, "[team diag] inserts: %.4g candidates passed the gate after the sorted first block (%.2f per query), in %.4g lock-step rounds of the wave (%.2f per query)\n",
+              (double)g[0], (double)g[0] / (double)n, (double)g[1], (double)g[1] / (double)n);
+    }
+    if (a.diag & 128) {
+      unsigned long long g[12];
+      OWLMI_HIP(hipMemcpy(g, counters_ + 28, sizeof g, hipMemcpyDeviceToHost));
+      for (int pass = 0; pass < 2; pass++) {
+        const unsigned long long *t4 = g + 8 * pass;
+        const double tt = (double)(t4[0] + t4[1] + t4[2] + t4[3]);
+        fprintf(stderr, "[team diag] %s pass, wave time: %.3g cycles in all; set-up %.1f%%  first group %.1f%%  other groups %.1f%%  epilogue %.1f%%\n",
+                pass ? "SELECT" : "COUNT", tt, 100 * t4[0] / tt, 100 * t4[1] / tt, 100 * t4[2] / tt, 100 * t4[3] / tt);
+      }
+    }
     if (a.diag & 32) {
       unsigned long long g[2];
       OWLMI_HIP(hipMemcpy(g, counters_ + 24, sizeof g, hipMemcpyDeviceToHost));
