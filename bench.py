@@ -1,17 +1,22 @@
 #!/usr/bin/env python3
-"""Contract benchmark: TrueKNN queries/sec on BASELINE.json config 2 (10 M uniform 3-D points, k=10).
+"""Contract benchmark of the neighbour-query path (BASELINE.json).
 
-    python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W              TrueKNN, 10 M uniform points per GPU, k=10 (configs[1])
+    python bench.py --workload dbscan                          RT-DBSCAN, 10 M Gaussian-mixture points, eps 0.01, minPts 4 (configs[2])
+    python bench.py --gpus N --scaling strong [--points 100000000]  one fixed point set cut into N Morton tiles (configs[3] with 1e8)
+    (N > 1: launched by torch.distributed.run, one rank per GPU, RCCL)
 
-A "step" is one whole radius-doubling TrueKNN solve (samples/s01-trueknn/hostCode.cpp:285-340) over
-the rank's resident batch: points and the LBVH are in HBM before the timed region, like the
-reference, which times "Build time" and "True KNN time" separately (hostCode.cpp:211,344).
-With N GPUs the point set is N x 10 M points cut into Morton tiles (weak scaling): every step is
-halo exchange over RCCL + halo-tree build + solve + termination all-reduce.
+A "step" is one whole solve over the rank's resident batch: points and the LBVH are in HBM before the
+timed region -- the reference, too, times "Build time" and "True KNN time" separately
+(samples/s01-trueknn/hostCode.cpp:211,344).  With N GPUs every step is halo selection + point-to-point
+exchange + halo-tree build + solve + termination all-reduce.
 
-Prints ONE JSON line on rank 0.  Extra keys: roofline (dominant kernel, HBM bound, algorithmic
-bytes per SURVEY 8d), cpu_baseline (the CPU checker's restatement timed on the host cores, rank 0,
-N=1 only).
+Prints ONE JSON line on rank 0.  Beside the contract's keys: `roofline` (dominant kernel, HBM bound,
+algorithmic bytes per SURVEY 8d, HIP-event kernel time; traffic and instruction counts from the committed
+rocprofv3 PMC passes if they were taken on THESE sources), `cpu_baseline` (the CPU checker's restatement on
+the host cores: rank 0, N = 1 only, bounded sample), `api_layout_writeback` (the solve with the reference's
+24-byte frameBuffer records), and for N > 1 `ranks`, `phase_ms`, `halo_points`, `halo_exchanges`.
+Exit status 1 (and "value": null) if the run's own parity spot check fails.
 """
 import argparse
 import json
@@ -26,8 +31,9 @@ if ROOT not in sys.path:
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
-N_POINTS = 10_000_000  # BASELINE.json configs[1]
+N_POINTS = 10_000_000  # BASELINE.json configs[1] / configs[2]
 K = 10
+DB_EPS, DB_MINPTS = 0.01, 4
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
@@ -36,14 +42,14 @@ def algorithmic_bytes(n, k, total_intersections, total_active_rounds):
     return 12 * total_active_rounds + 12 * total_intersections + 8 * k * n
 
 
-def cpu_baseline(xyz, k, r0, seconds_budget=25.0):
+def cpu_baseline_trueknn(xyz, k, r0):
     """The CPU checker (oracle/, reference semantics) on a bounded sample of the same workload."""
     import oracle
 
     n = len(xyz)
     threads = oracle.num_threads()
     rng = np.random.default_rng(7)
-    sample = 2_000_000  # ~10 s of CPU work on the GPU box: bounded, but long enough to average out scheduling noise
+    sample = min(2_000_000, n)  # ~10 s of CPU work on the GPU box: bounded, but long enough to average out scheduling noise
     q = np.sort(rng.choice(n, sample, replace=False)).astype(np.int32)
     t0 = time.perf_counter()
     ref = oracle.trueknn(xyz, k, r0, query_ids=q)
@@ -59,7 +65,7 @@ def cpu_baseline(xyz, k, r0, seconds_budget=25.0):
                       sample, n, threads, ref["query_seconds"], wall),
         "rounds": int(ref["rounds"]),
     }
-    # exact brute force (the north_star's "CPU brute-force"), bounded: 2000 queries x 10 M points
+    # exact brute force (the north_star's "CPU brute-force"), bounded: 2000 queries x n points
     qb = q[:2000]
     t0 = time.perf_counter()
     oracle.bruteforce_knn(xyz, k, qb)
@@ -68,14 +74,88 @@ def cpu_baseline(xyz, k, r0, seconds_budget=25.0):
     return out, ref, q
 
 
+def cpu_baseline_dbscan(xyz, eps, min_pts, budget_s=30.0):
+    """the spec's grid DBSCAN on all host cores (oracle.dbscan_threaded).  The whole set
+    if a timed 5 % slab says it fits the budget, else the largest leading share of the points that does (clusters
+    of a mixture keep their shape, the density falls with the share: the rate is then an upper bound)."""
+    import oracle
+
+    n = len(xyz)
+    threads = oracle.num_threads()
+    probe = max(n // 20, 1)
+    t0 = time.perf_counter()
+    oracle.dbscan_threaded(xyz[:probe], eps, min_pts)
+    dt = time.perf_counter() - t0
+    # work per point grows with the density, i.e. with the share taken: cost(share) ~ share^2 * cost(all)
+    est_full = dt * (n / probe) ** 2
+    share = 1.0 if est_full <= budget_s else max((budget_s / est_full) ** 0.5, probe / n)
+    m = min(n, max(int(n * share), probe))
+    t0 = time.perf_counter()
+    r = oracle.dbscan_threaded(xyz[:m], eps, min_pts)
+    wall = time.perf_counter() - t0
+    return {
+        "value": m / wall,
+        "unit": "points/s",
+        "cores": threads,
+        "kind": "port",
+        "sample": "the first %d of the %d points (%s) through oracle/dbscan_oracle.c:dbref_dbscan_mt (OpenMP, %d threads): "
+                  "%.2fs wall = grid %.2f + core flags %.2f + unions %.2f + labels %.2f; %d clusters there" % (
+                      m, n, "the whole workload" if m == n else "a share: lower density than the workload, so an upper bound on the CPU rate",
+                      threads, wall, r["seconds"][0], r["seconds"][1], r["seconds"][2], r["seconds"][3], r["clusters"]),
+    }, r, m
+
+
+def committed_profile(kernel_name, n_local, k):
+    """Per-launch PMC figures from profiles/hbm_traffic.json, if they were measured on these very sources."""
+    from owlraytracing_amd import _lib
+
+    path = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+    if not os.path.exists(path):
+        return None, "no profiles/hbm_traffic.json"
+    try:
+        rec = json.load(open(path)).get("%s:n=%d:k=%d" % (kernel_name, n_local, k))
+    except Exception as e:  # a damaged file is not a reason to lose the bench line
+        return None, "profiles/hbm_traffic.json unreadable: %s" % e
+    if not rec:
+        return None, "no PMC record for this kernel and size"
+    have, want = rec.get("source_sha16"), _lib.source_fingerprint()
+    if have != want:
+        return None, "the committed PMC record was taken on other kernel sources (%s, these are %s): re-run scripts/profile_gpu.sh" % (have, want)
+    return rec, None
+
+
+def copy_bandwidth(dev):
+    """A plain device-to-device copy of 1 GiB on this GPU, read + write bytes over the best of 5 timings (context
+    for the roofline, SURVEY 8d: "report against the measured stream peak as well")."""
+    src = torch.empty(1 << 28, dtype=torch.float32, device=dev)
+    dst = torch.empty_like(src)
+    best = None
+    for _ in range(5):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        dst.copy_(src)
+        e1.record()
+        e1.synchronize()
+        t = e0.elapsed_time(e1)
+        best = t if best is None else min(best, t)
+    del src, dst
+    return 2 * (1 << 28) * 4 / (best * 1e-3) / 1e9
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--n", type=int, default=N_POINTS, help="points per GPU (default: BASELINE config 2)")
+    ap.add_argument("--workload", choices=("trueknn", "dbscan"), default="trueknn")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
+                    help="weak: --points per GPU; strong: --points in all, cut into one Morton tile per GPU")
+    # (not "--n": torch.distributed.run's own parser stumbles over script options that abbreviate its --nnodes / --nproc-per-node)
+    ap.add_argument("--points", dest="n", type=int, default=N_POINTS, help="points per GPU (weak) or in all (strong); default: BASELINE config 2")
     ap.add_argument("--k", type=int, default=K)
-    ap.add_argument("--kernel", type=int, default=0, help="0 auto, 1 lane, 2 wave")
+    ap.add_argument("--eps", type=float, default=DB_EPS)
+    ap.add_argument("--min-pts", type=int, default=DB_MINPTS)
+    ap.add_argument("--kernel", type=int, default=0, help="0 auto, 1 lane, 2 wave, 3 team")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--sharded", action="store_true", help="use the Morton-tile / halo-exchange driver even for one rank")
     args = ap.parse_args()
@@ -97,8 +177,13 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
-    n, k = args.n, args.k
+    k = args.k
     sharded = world > 1 or args.sharded
+    dbscan = args.workload == "dbscan"
+    n_total = args.n if (args.scaling == "strong" or not sharded) else args.n * world
+    eps32 = float(np.float32(args.eps))
+    dist = None
+    extra = {}
     if sharded:
         import torch.distributed as dist
 
@@ -114,26 +199,43 @@ def main():
                 dist.init_process_group("nccl", device_id=dev)
             else:
                 dist.init_process_group(backend)
-        n_total = n * world
-        r0 = datasets.start_radius(n_total, k)
         solver = tkd.ShardedTrueKNN(dev, kernel=args.kernel)
-        solver.load_counter_based(n_total, seed=0)  # one-time: generate, Morton-tile, build own trees
-        step = lambda: solver.solve(k, r0)  # noqa: E731
+        if dbscan:
+            # every rank draws the whole mixture's slice it is given (the generator is sequential: slices of one stream)
+            lo, hi = n_total * rank // world, n_total * (rank + 1) // world
+            pts = datasets.gaussian_mixture3d(n_total, components=64, sigma=0.02, seed=1)[lo:hi]
+            solver.load_points(torch.from_numpy(pts), torch.arange(lo, hi, dtype=torch.int32))
+            step = lambda: solver.dbscan(eps32, args.min_pts)["info"]  # noqa: E731
+            r0 = None
+        else:
+            r0 = datasets.start_radius(n_total, k)
+            solver.load_counter_based(n_total, seed=0)  # one-time: generate, Morton-tile, build own trees
+            step = lambda: solver.solve(k, r0)  # noqa: E731
+        n_local = len(solver.points)
     else:
-        dist = None
-        n_total = n
-        xyz_host = datasets.uniform3d(n, seed=0)
-        r0 = datasets.start_radius(n, k)
+        if dbscan:
+            xyz_host = datasets.gaussian_mixture3d(n_total, components=64, sigma=0.02, seed=1)
+            r0 = None
+        else:
+            xyz_host = datasets.uniform3d(n_total, seed=0)
+            r0 = datasets.start_radius(n_total, k)
         pts = torch.from_numpy(xyz_host).to(dev)
         eng = TrueKNN(device=local_rank)
         build_info = eng.build(pts)
         build_info = eng.build(pts)  # second build: steady-state build time (first one pays allocations)
         out = {}
+        n_local = n_total
 
-        def step():
-            r = eng.solve(k, r0, kernel=args.kernel, out=out)
-            out.update({kk: v for kk, v in r.items() if kk != "info"})
-            return r["info"]
+        if dbscan:
+            def step():
+                r = eng.dbscan(eps32, args.min_pts)
+                out.update({kk: v for kk, v in r.items() if kk != "info"})
+                return r["info"]
+        else:
+            def step():
+                r = eng.solve(k, r0, kernel=args.kernel, out=out)
+                out.update({kk: v for kk, v in r.items() if kk != "info"})
+                return r["info"]
 
     for _ in range(args.warmup):
         info = step()
@@ -152,31 +254,101 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        ones = torch.ones(1, dtype=torch.int64, device=dev)
+        dist.all_reduce(ones, op=dist.ReduceOp.SUM)
+        extra["ranks"] = int(ones.item())
+        # per-phase wall times of two more, instrumented steps (a device synchronisation after every phase, so
+        # they are not part of the timed region); maximum over the ranks of each phase's mean
+        if not dbscan:
+            solver.profile = True
+            ph = [solver.solve(k, r0)["phase_ms"] for _ in range(2)]
+            solver.profile = False
+            names = sorted(ph[0])
+            v = torch.tensor([float(np.mean([p[nm] for p in ph])) for nm in names], dtype=torch.float64, device=dev)
+            dist.all_reduce(v, op=dist.ReduceOp.MAX)
+            extra["phase_ms"] = {nm: float(x) for nm, x in zip(names, v.tolist())}
+        last = infos[-1]
+        hp = torch.tensor([int(last.get("halo_points", 0))], dtype=torch.int64, device=dev)
+        dist.all_reduce(hp, op=dist.ReduceOp.SUM)
+        extra["halo_points"] = int(hp.item())
+        extra["halo_exchanges"] = int(last.get("halo_exchanges", 1 if dbscan else 0))
+        if dbscan:
+            extra["label_rounds"] = int(last.get("rounds", 0))
 
     ms_per_step = elapsed / args.steps * 1e3
     value = n_total * args.steps / elapsed
     info = infos[-1]
+    tiles = "" if not sharded else "; %d Morton tiles, RCCL halo exchange" % world
+    if dbscan:
+        line = dbscan_line(args, info, infos, value, ms_per_step, n_total, n_local, world, sharded, eps32, tiles)
+    else:
+        line = trueknn_line(args, info, infos, value, ms_per_step, n_total, n_local, world, sharded, r0, tiles)
+    line["scaling"] = args.scaling if sharded else "weak"
+    line.update(extra)
+    failed = False
+    if not sharded:
+        line["build_ms"] = float(build_info["build_ms"])
+        line["tree_bytes"] = int(build_info["device_bytes"])
+    if rank == 0:
+        line["roofline"]["measured_copy_GBps"] = copy_bandwidth(dev)
+    if rank == 0 and not sharded and not dbscan:
+        # the reference's result layout (24-byte Neigh records, GeomTypes.h:22-28) is an artefact of
+        # its API; its write-back cost is reported apart from the compact rows the step writes
+        fb_ms = []
+        for _ in range(3):
+            r = eng.solve(k, r0, kernel=args.kernel, want_fb=True)
+            fb_ms.append(float(r["info"]["solve_ms"]))
+        del r
+        plain = float(np.mean([i["solve_ms"] for i in infos]))
+        line["api_layout_writeback"] = {
+            "solve_ms_with_frameBuffer": float(np.min(fb_ms)),
+            "solve_ms_compact_rows_only": plain,
+            "extra_ms": float(np.min(fb_ms)) - plain,
+            "frameBuffer_bytes": 24 * k * n_total,
+            "note": "one solve writing idx/dist/intersections AND the n*k 24-byte records the reference's host loop reads",
+        }
+    if rank == 0 and not sharded and not args.no_cpu_baseline:
+        if dbscan:
+            cb, ref, m = cpu_baseline_dbscan(xyz_host, eps32, args.min_pts)
+            line["cpu_baseline"] = cb
+            if m == n_total:  # the whole set went through the checker: compare the benchmarked run with it
+                ok = (np.array_equal(out["labels"].cpu().numpy(), ref["labels"]) and np.array_equal(out["core"].cpu().numpy(), ref["core"]))
+                line["parity_spot_check"] = "labels and core flags of all %d points equal the CPU spec's" % m if ok else "MISMATCH"
+                failed = not ok
+            else:
+                # core flags of the first m points are density-dependent: no comparison on a share; the full-size parity
+                # test is tests/test_dbscan.py::test_config3_full_size (-m gpu)
+                line["parity_spot_check"] = "not applicable on a share of the set (see tests/test_dbscan.py, full size)"
+        else:
+            cb, ref, q = cpu_baseline_trueknn(xyz_host, k, r0)
+            line["cpu_baseline"] = cb
+            # the sample doubles as a parity spot check of the benchmarked run itself
+            ql = torch.from_numpy(q.astype(np.int64)).to(dev)
+            ok = (np.array_equal(out["idx"][ql].cpu().numpy(), ref["idx"][q])
+                  and np.array_equal(out["dist"][ql].cpu().numpy(), ref["dist"][q])
+                  and np.array_equal(out["intersections"][ql].cpu().numpy(), ref["intersections"][q]))
+            line["parity_spot_check"] = "bit-exact on %d sampled rows" % len(q) if ok else "MISMATCH"
+            failed = not ok
+    if failed:
+        line["value"] = None  # a wrong result has no throughput
+    if rank == 0:
+        print(json.dumps(line))
+    if dist is not None:
+        dist.destroy_process_group()
+    if failed:
+        sys.exit(1)
+
+
+def trueknn_line(args, info, infos, value, ms_per_step, n_total, n_local, world, sharded, r0, tiles):
+    k = args.k
     kern_ms = float(np.mean([i["dominant_kernel_ms"] for i in infos]))
     total_isect = int(info["total_intersections"])
     total_rounds_active = int(info["total_active_rounds"])
-    n_local = len(solver.points) if sharded else n
     alg_bytes = algorithmic_bytes(n_local, k, total_isect, total_rounds_active)
     launches = max(int(info["dominant_kernel_launches"]), 1)
     achieved = alg_bytes / launches / (kern_ms * 1e-3) / 1e9
     kernel_name = {1: "lane_round_kernel", 2: "wave_packet_kernel", 3: "team_kernel"}.get(int(info["kernel_used"]), "?")
-    # HBM traffic from the PMC counters is collected in separate rocprofv3 passes (profiles/);
-    # attach the committed per-launch figure when it was measured for this exact workload.
-    traffic, issue = None, {}
-    tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-    if os.path.exists(tpath):
-        try:
-            rec = json.load(open(tpath)).get("%s:n=%d:k=%d" % (kernel_name, n_local, k))
-            if rec:
-                traffic = rec["bytes_per_launch"]
-                issue = {k2: rec[k2] for k2 in ("valu_wave_instructions_per_launch", "salu_wave_instructions_per_launch") if k2 in rec}
-        except Exception:
-            traffic = None
-
+    rec, why_not = committed_profile(kernel_name, n_local, k)
     line = {
         "metric": "kNN queries/sec (10M pts, k=10)",
         "value": value,
@@ -191,9 +363,12 @@ def main():
         "dtype": "f32",
         "data": "synthetic",
         "config": {
-            "workload": "TrueKNN on %d uniform-random 3-D points per GPU (numpy default_rng(0), [0,1)^3), k=%d, "
-                        "start radius 0.25*(k/n)^(1/3)=%.6g; BASELINE.json configs[1]%s" % (
-                            n_local, k, r0, "" if not sharded else "; %d Morton tiles, RCCL halo exchange" % world),
+            "workload": "TrueKNN on %d uniform-random 3-D points%s (%s), k=%d, start radius 0.25*(k/n)^(1/3)=%.6g; "
+                        "BASELINE.json configs[%d]%s" % (
+                            n_total if args.scaling == "strong" or not sharded else n_local,
+                            " in all" if args.scaling == "strong" and sharded else (" per GPU" if sharded else ""),
+                            "counter-based Philox(0), [0,1)^3" if sharded else "numpy default_rng(0), [0,1)^3", k, r0,
+                            3 if n_total >= 100_000_000 and sharded else 1, tiles),
             "n_points_total": n_total,
             "k": k,
             "start_radius": r0,
@@ -211,59 +386,107 @@ def main():
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS,
-            "traffic": traffic,
+            "traffic": rec["bytes_per_launch"] if rec else None,
             "algorithmic_bytes_per_launch": alg_bytes // launches,
             "launches_per_step": launches,
             "kernel_ms": kern_ms,
             "timing": "HIP events on the launch stream, recorded inside libowl_mi355x.so around the kernel",
         },
     }
-    if issue.get("valu_wave_instructions_per_launch"):
-        # the bound that actually binds: vector instruction issue.  Instruction counts come
-        # from the committed rocprofv3 PMC pass of this workload, the time is this run's; a wave64 VALU
-        # instruction occupies its SIMD for 4 cycles, 4 SIMDs per CU.
-        props = torch.cuda.get_device_properties(dev)
+    if why_not:
+        line["roofline"]["traffic_note"] = why_not
+    if rec and rec.get("valu_wave_instructions_per_launch"):
+        # what the kernel is really limited by: instruction issue and the latencies between
+        # instructions, not HBM.  Counts and wait shares come from the committed PMC passes (same sources, checked
+        # above), the time is this run's.  A wave64 VALU instruction occupies its SIMD for 2 cycles
+        # (MI355X_MICROARCH.md, "Wave scheduling"); the instructions of this kernel that read or write lane masks,
+        # cross lanes or compare 64-bit keys take about 4 (scripts/microbench/issue_rate.hip), so the first
+        # figure is a lower bound of the pipe's occupancy.
+        props = torch.cuda.get_device_properties(torch.cuda.current_device())
         clock_hz = float(getattr(props, "clock_rate", 2400000)) * 1e3
         simds = props.multi_processor_count * 4
-        line["roofline"]["issue"] = {
-            "valu_wave_instructions_per_launch": issue["valu_wave_instructions_per_launch"],
-            "salu_wave_instructions_per_launch": issue.get("salu_wave_instructions_per_launch"),
-            "valu_busy_frac": issue["valu_wave_instructions_per_launch"] * 4.0 / (simds * clock_hz * kern_ms * 1e-3),
+        cyc = simds * clock_hz * kern_ms * 1e-3
+        issue = {
+            "valu_wave_instructions_per_launch": rec["valu_wave_instructions_per_launch"],
+            "salu_wave_instructions_per_launch": rec.get("salu_wave_instructions_per_launch"),
+            "valu_issue_frac_at_2_cycles": rec["valu_wave_instructions_per_launch"] * 2.0 / cyc,
             "clock_mhz": clock_hz / 1e6,
-            "source": "profiles/hbm_traffic.json (rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU on this workload)",
+            "source": "profiles/hbm_traffic.json (rocprofv3 --pmc passes over this workload, sources %s)" % rec.get("source_sha16"),
         }
-    if not sharded:
-        line["build_ms"] = float(build_info["build_ms"])
-        line["tree_bytes"] = int(build_info["device_bytes"])
-    if rank == 0:
-        # context for the roofline ("report against the measured stream peak as well"): a plain
-        # device-to-device copy of 1 GiB on this GPU, read + write bytes over the best of 5 timings
-        src = torch.empty(1 << 28, dtype=torch.float32, device=dev)
-        dst = torch.empty_like(src)
-        best = None
-        for _ in range(5):
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            dst.copy_(src)
-            e1.record()
-            e1.synchronize()
-            t = e0.elapsed_time(e1)
-            best = t if best is None else min(best, t)
-        line["roofline"]["measured_copy_GBps"] = 2 * src.numel() * 4 / (best * 1e-3) / 1e9
-        del src, dst
-    if rank == 0 and not sharded and not args.no_cpu_baseline:
-        cb, ref, q = cpu_baseline(xyz_host, k, r0)
-        line["cpu_baseline"] = cb
-        # the sample doubles as a parity spot check of the benchmarked run itself
-        ql = torch.from_numpy(q.astype(np.int64)).to(dev)
-        ok = (np.array_equal(out["idx"][ql].cpu().numpy(), ref["idx"][q])
-              and np.array_equal(out["dist"][ql].cpu().numpy(), ref["dist"][q])
-              and np.array_equal(out["intersections"][ql].cpu().numpy(), ref["intersections"][q]))
-        line["parity_spot_check"] = "bit-exact on %d sampled rows" % len(q) if ok else "MISMATCH"
-    if rank == 0:
-        print(json.dumps(line))
-    if dist is not None:
-        dist.destroy_process_group()
+        for kk in ("wave_wait_frac", "wave_issue_stall_frac", "wave_active_frac", "scalar_pipe_instructions_per_launch",
+                   "lds_instructions_per_launch"):
+            if kk in rec:
+                issue[kk] = rec[kk]
+        if rec.get("scalar_pipe_instructions_per_launch"):
+            # one scalar pipe per CU, about one instruction per cycle (issue_rate.hip: 4.4 cycles per instruction per SIMD)
+            issue["scalar_pipe_frac"] = rec["scalar_pipe_instructions_per_launch"] / (props.multi_processor_count * clock_hz * kern_ms * 1e-3)
+        line["roofline"]["issue"] = issue
+    return line
+
+
+def dbscan_line(args, info, infos, value, ms_per_step, n_total, n_local, world, sharded, eps32, tiles):
+    line = {
+        "metric": "RT-DBSCAN points/sec (10M Gaussian-mixture pts, eps=0.01, minPts=4)",
+        "value": value,
+        "unit": "points/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": ms_per_step,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {
+            "workload": "RT-DBSCAN on %d 3-D points of a 64-component Gaussian mixture (sigma 0.02, numpy default_rng(1)), eps=%.6g, "
+                        "minPts=%d; BASELINE.json configs[2]%s" % (n_total, eps32, args.min_pts, tiles),
+            "n_points_total": n_total,
+            "eps": eps32,
+            "min_pts": args.min_pts,
+            "parallelism": "1 GPU" if not sharded else "%d Morton tiles + 2-eps halo + label propagation" % world,
+        },
+        "clusters": int(info.get("clusters", -1)),
+    }
+    if sharded:
+        # the sharded driver reports clusters / rounds / halo only; the per-kernel figures are the tiles' own
+        line["roofline"] = {"bound": "hbm", "kernel": "db_union_kernel", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                            "frac": None, "traffic": None, "note": "per-kernel counters are reported by the single-GPU run"}
+        return line
+    # the dominant traversal kernel of the call, by its own HIP-event time
+    names = {"core_ms": ("db_core_kernel", "core_point_tests", 1), "union_ms": ("db_union_kernel", "union_point_tests", 0),
+             "label_ms": ("db_label_kernel", "label_point_tests", 4)}
+    mean = {nm: float(np.mean([i[nm] for i in infos])) for nm in names}
+    dom = max(mean, key=mean.get)
+    kernel_name, tests_key, out_bytes = names[dom]
+    # SURVEY 8(d) carried over to DBSCAN: 12 B per point whose distance to a query is computed (the query's own
+    # 12 B once per traversal) + what the kernel writes per point (core flag / nothing / label)
+    alg_bytes = 12 * int(info[tests_key]) + 12 * n_local + out_bytes * n_local
+    achieved = alg_bytes / (mean[dom] * 1e-3) / 1e9
+    line["roofline"] = {
+        "bound": "hbm",
+        "kernel": kernel_name,
+        "achieved": achieved,
+        "peak": HBM_PEAK_GBS,
+        "unit": "GB/s",
+        "frac": achieved / HBM_PEAK_GBS,
+        "traffic": None,
+        "algorithmic_bytes_per_launch": alg_bytes,
+        "launches_per_step": 1,
+        "kernel_ms": mean[dom],
+        "timing": "HIP events on the launch stream, recorded inside libowl_mi355x.so around the kernel",
+        "all_kernels_ms": {"core_flags": mean["core_ms"], "unions": mean["union_ms"], "labels": mean["label_ms"],
+                           "whole_call": float(np.mean([i["solve_ms"] for i in infos]))},
+        "point_distance_tests": {"core_flags": int(info["core_point_tests"]), "unions": int(info["union_point_tests"]),
+                                 "labels": int(info["label_point_tests"])},
+        "node_box_tests": int(info["node_tests"]),
+    }
+    rec, why_not = committed_profile(kernel_name, n_local, args.min_pts)
+    if rec:
+        line["roofline"]["traffic"] = rec["bytes_per_launch"]
+    elif why_not:
+        line["roofline"]["traffic_note"] = why_not
+    return line
 
 
 if __name__ == "__main__":

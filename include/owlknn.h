@@ -142,7 +142,11 @@ typedef struct {
   int32_t kernel;
   int32_t max_rounds;
   int32_t allow_unfinished;
-  int32_t reserved_;
+  int32_t phase; /* 0: every query.  1: only the queries NO point of another tile can reach within the radius the last
+                    tknnHaloSelect count pass was given boxes for ("interior"), searched in the own tree alone -- the call may
+                    run on its own stream and host thread while the halo is exchanged and tknnSetHalo builds its tree.
+                    2: the other ("boundary") queries, own + halo tree; rows and levels of a phase-1 call are kept.
+                    Team kernels only (k <= 64). */
   int32_t *d_idx;
   float *d_dist;
   int64_t *d_intersections;
@@ -178,7 +182,16 @@ TKNN_API int tknnRepairExact(tknnEngine e, int k, float start_radius, const int3
  *   NULL; asking for it disables the early exit of the core test).  Call tknnBuild first. */
 typedef struct {
   int32_t clusters;
-  float solve_ms;
+  float solve_ms;    /* HIP events around all launches of the call */
+  float core_ms;     /* the three traversal kernels (events on the launch stream): core flags, */
+  float union_ms;    /* unions of core neighbours (the dominant kernel on dense sets),        */
+  float label_ms;    /* labels of border points (tknnDbscanAssign: its one traversal)         */
+  int32_t pad_;
+  int64_t node_tests;         /* tree-node box tests over the three traversals */
+  int64_t point_tests;        /* points whose distance to a query was computed (12 algorithmic bytes each) */
+  int64_t core_point_tests;   /* ... per traversal */
+  int64_t union_point_tests;
+  int64_t label_point_tests;
 } tknnDbscanInfo;
 TKNN_API int tknnDbscan(tknnEngine e, float eps, int min_pts, int32_t *d_labels, uint8_t *d_core,
                         int32_t *d_counts, tknnDbscanInfo *info, void *stream);

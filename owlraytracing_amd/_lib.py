@@ -51,7 +51,7 @@ class SolveOptions(ctypes.Structure):
         ("kernel", ctypes.c_int32),
         ("max_rounds", ctypes.c_int32),
         ("allow_unfinished", ctypes.c_int32),
-        ("reserved_", ctypes.c_int32),
+        ("phase", ctypes.c_int32),
         ("d_idx", ctypes.c_void_p),
         ("d_dist", ctypes.c_void_p),
         ("d_intersections", ctypes.c_void_p),
@@ -61,10 +61,13 @@ class SolveOptions(ctypes.Structure):
 
 
 class DbscanInfo(ctypes.Structure):
-    _fields_ = [("clusters", ctypes.c_int32), ("solve_ms", ctypes.c_float)]
+    _fields_ = [("clusters", ctypes.c_int32), ("solve_ms", ctypes.c_float), ("core_ms", ctypes.c_float),
+                ("union_ms", ctypes.c_float), ("label_ms", ctypes.c_float), ("pad_", ctypes.c_int32),
+                ("node_tests", ctypes.c_int64), ("point_tests", ctypes.c_int64), ("core_point_tests", ctypes.c_int64),
+                ("union_point_tests", ctypes.c_int64), ("label_point_tests", ctypes.c_int64)]
 
     def as_dict(self):
-        return {name: getattr(self, name) for name, _ in self._fields_}
+        return {name: getattr(self, name) for name, _ in self._fields_ if name != "pad_"}
 
 
 class BuildInfo(ctypes.Structure):
@@ -128,3 +131,22 @@ def load():
 def check(rc):
     if rc != 0:
         raise TknnError(rc, (load().tknnLastError() or b"").decode())
+
+
+def source_fingerprint():
+    """16 hex digits naming the native sources the library is built from (csrc/ and include/): what a committed
+    rocprofv3 record must carry for bench.py to attach it to a run (profiles/hbm_traffic.json)."""
+    import glob
+    import hashlib
+
+    root = os.path.dirname(_HERE)
+    files = sorted(glob.glob(os.path.join(_HERE, "csrc", "*.hip")) + glob.glob(os.path.join(_HERE, "csrc", "*.h"))
+                   + glob.glob(os.path.join(_HERE, "csrc", "*.cpp")) + glob.glob(os.path.join(_HERE, "csrc", "Makefile"))
+                   + glob.glob(os.path.join(root, "include", "**", "*.h"), recursive=True))
+    h = hashlib.sha256()
+    for f in files:
+        h.update(os.path.relpath(f, root).encode())
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+

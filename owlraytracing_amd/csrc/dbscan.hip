@@ -28,6 +28,8 @@
 
 #include <hipcub/hipcub.hpp>
 
+#include <cstring>
+
 namespace owlmi {
 namespace {
 
@@ -47,7 +49,29 @@ struct DbArgs {
   int32_t *labels;       // per caller index
   const int32_t *next_core;  // per sorted slot (+1 sentinel): first core slot at or after it, n if none
   float eps_in2, eps_out2;   // eps^2 (1 -+ 1e-5): below / above these, fp32 distance arithmetic cannot disagree
+  // work counters, per traversal kernel k (0 core flags, 1 unions, 2 labels / assign): [2k] tree nodes
+  // tested, [2k + 1] points whose distance to a query was computed (12 algorithmic bytes each)
+  unsigned long long *stats;
 };
+
+// a workgroup's counts into the kernel's two counters: wave sums, one LDS atomic per wave, one global
+// atomic per workgroup (every thread of the workgroup must call it)
+__device__ __forceinline__ void db_add_stats(unsigned long long *stats, unsigned long long *blk, uint32_t nodes, uint32_t points) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    nodes += __shfl_xor(nodes, off);
+    points += __shfl_xor(points, off);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    atomicAdd(&blk[0], (unsigned long long)nodes);
+    atomicAdd(&blk[1], (unsigned long long)points);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    atomicAdd(&stats[0], blk[0]);
+    atomicAdd(&stats[1], blk[1]);
+  }
+}
 
 // squared distances from q to the farthest and the nearest point of a box
 __device__ __forceinline__ void box_dist2(const LbvhNode &nd, const LbvhPoint &q, float &far2, float &near2) {
@@ -93,7 +117,8 @@ __device__ __forceinline__ void uf_unite(int32_t *parent, int32_t a, int32_t b) 
 // `settled(row)` may say that the group a tight node's first core point stands for needs no look
 // (the union kernel: already in my set), sparing the distance tests and the probe.
 template <typename S, typename F>
-__device__ __forceinline__ void for_each_core_group(const DbArgs &a, const LbvhPoint &q, int32_t own_slot, S settled, F f) {
+__device__ __forceinline__ void for_each_core_group(const DbArgs &a, const LbvhPoint &q, int32_t own_slot, S settled, F f,
+                                                    uint32_t &node_tests, uint32_t &point_tests) {
   const LbvhView &bvh = a.bvh;
   const float r = a.eps_wide;
   int32_t ref = bvh.root;
@@ -105,6 +130,7 @@ __device__ __forceinline__ void for_each_core_group(const DbArgs &a, const LbvhP
     if (probe_rep >= 0 && ref == probe_exit) probe_rep = -1;  // left the probed subtree without a hit
     if (ref >= 0) {
       const LbvhNode nd = bvh.nodes[ref];
+      node_tests++;
       const bool hit = (nd.lo[0] - r <= q.x) & (q.x <= nd.hi[0] + r) & (nd.lo[1] - r <= q.y) & (q.y <= nd.hi[1] + r) &
                        (nd.lo[2] - r <= q.z) & (q.z <= nd.hi[2] + r);
       if (!hit) {
@@ -145,6 +171,7 @@ __device__ __forceinline__ void for_each_core_group(const DbArgs &a, const LbvhP
       const int32_t slot = ~ref;
       if (a.core_sorted[slot] && slot != own_slot) {
         const LbvhPoint p = bvh.points[slot];
+        point_tests++;
         if (knn_sqrt(knn_dist2(p.x, p.y, p.z, q.x, q.y, q.z)) <= a.eps) {
           if (probe_rep >= 0) {
             f(probe_rep);
@@ -160,9 +187,7 @@ __device__ __forceinline__ void for_each_core_group(const DbArgs &a, const LbvhP
   }
 }
 
-__global__ void __launch_bounds__(kDbBlock) db_core_kernel(DbArgs a) {
-  const int32_t t = blockIdx.x * kDbBlock + threadIdx.x;
-  if (t >= a.bvh.n) return;
+__device__ __forceinline__ void db_core_body(const DbArgs &a, int32_t t, uint32_t &node_tests, uint32_t &point_tests) {
   const LbvhView &bvh = a.bvh;
   const LbvhPoint q = bvh.points[t];
   int32_t cnt = 0;
@@ -190,6 +215,7 @@ __global__ void __launch_bounds__(kDbBlock) db_core_kernel(DbArgs a) {
   while (ref != LBVH_END && cnt < stop_at) {
     if (ref >= 0) {
       const LbvhNode nd = bvh.nodes[ref];
+      node_tests++;
       const bool hit = (nd.lo[0] - r <= q.x) & (q.x <= nd.hi[0] + r) & (nd.lo[1] - r <= q.y) & (q.y <= nd.hi[1] + r) &
                        (nd.lo[2] - r <= q.z) & (q.z <= nd.hi[2] + r);
       if (hit) {
@@ -207,6 +233,7 @@ __global__ void __launch_bounds__(kDbBlock) db_core_kernel(DbArgs a) {
     } else {
       const int32_t slot = ~ref;
       const LbvhPoint p = bvh.points[slot];
+      point_tests++;
       if (knn_sqrt(knn_dist2(p.x, p.y, p.z, q.x, q.y, q.z)) <= a.eps) cnt++;
       ref = bvh.rope_leaf[slot];
     }
@@ -219,6 +246,16 @@ __global__ void __launch_bounds__(kDbBlock) db_core_kernel(DbArgs a) {
   if (a.core) a.core[row] = is_core;
   if (a.counts) a.counts[row] = cnt;
   a.parent[row] = row;
+}
+
+__global__ void __launch_bounds__(kDbBlock) db_core_kernel(DbArgs a) {
+  __shared__ unsigned long long blk_stats[2];
+  if (threadIdx.x < 2) blk_stats[threadIdx.x] = 0ull;
+  __syncthreads();
+  uint32_t node_tests = 0, point_tests = 0;
+  const int32_t t = blockIdx.x * kDbBlock + threadIdx.x;
+  if (t < a.bvh.n) db_core_body(a, t, node_tests, point_tests);
+  db_add_stats(a.stats + 0, blk_stats, node_tests, point_tests);
 }
 
 // next_core[s] = first core slot >= s (n if none): with rank[s] = number of core slots before s (an
@@ -244,18 +281,8 @@ __global__ void __launch_bounds__(kDbBlock) db_next_core_kernel(DbArgs a, const 
   next_core[t] = v < a.bvh.n ? v : a.bvh.n;
 }
 
-__global__ void __launch_bounds__(kDbBlock) db_union_kernel(DbArgs a) {
-  // The 256 Morton-consecutive points of a workgroup mostly share a tight node and meet the same
-  // neighbouring tight nodes: every (my group, other group) pair would be united hundreds of times,
-  // each a pair of union-find walks through global atomics.  A direct-mapped LDS table of the pairs
-  // this workgroup has already taken care of drops the repeats (a stale or raced entry only costs a
-  // redundant unite; the pair that set an entry is united by the lane that set it).
-  constexpr int kPairs = 2048;
-  __shared__ unsigned long long seen[kPairs];
-  for (int i = threadIdx.x; i < kPairs; i += kDbBlock) seen[i] = ~0ull;
-  __syncthreads();
-  const int32_t t = blockIdx.x * kDbBlock + threadIdx.x;
-  if (t >= a.bvh.n || !a.core_sorted[t]) return;
+__device__ __forceinline__ void db_union_body(const DbArgs &a, int32_t t, unsigned long long *seen, int kPairs, uint32_t &node_tests,
+                                              uint32_t &point_tests) {
   const LbvhView &bvh = a.bvh;
   const LbvhPoint q = bvh.points[t];
   const int32_t row = bvh.prim_id[t];
@@ -265,6 +292,7 @@ __global__ void __launch_bounds__(kDbBlock) db_union_kernel(DbArgs a) {
   int32_t node = bvh.root;
   while (node >= 0) {
     const LbvhNode nd = bvh.nodes[node];
+    node_tests++;
     if (node_is_tight(nd, a.eps_in2)) {
       const int32_t s = a.next_core[lbvh_first(node, nd.other)];  // <= t: I am core and inside
       if (s != t) {
@@ -304,7 +332,26 @@ __global__ void __launch_bounds__(kDbBlock) db_union_kernel(DbArgs a) {
         *(volatile unsigned long long *)slot = key;
         uf_unite(a.parent, mine, other);
         my_root = uf_find(a.parent, mine);
-      });
+      },
+      node_tests, point_tests);
+}
+
+__global__ void __launch_bounds__(kDbBlock) db_union_kernel(DbArgs a) {
+  // The 256 Morton-consecutive points of a workgroup mostly share a tight node and meet the same
+  // neighbouring tight nodes: every (my group, other group) pair would be united hundreds of times,
+  // each a pair of union-find walks through global atomics.  A direct-mapped LDS table of the pairs
+  // this workgroup has already taken care of drops the repeats (a stale or raced entry only costs a
+  // redundant unite; the pair that set an entry is united by the lane that set it).
+  constexpr int kPairs = 2048;
+  __shared__ unsigned long long seen[kPairs];
+  __shared__ unsigned long long blk_stats[2];
+  for (int i = threadIdx.x; i < kPairs; i += kDbBlock) seen[i] = ~0ull;
+  if (threadIdx.x < 2) blk_stats[threadIdx.x] = 0ull;
+  __syncthreads();
+  uint32_t node_tests = 0, point_tests = 0;
+  const int32_t t = blockIdx.x * kDbBlock + threadIdx.x;
+  if (t < a.bvh.n && a.core_sorted[t]) db_union_body(a, t, seen, kPairs, node_tests, point_tests);
+  db_add_stats(a.stats + 2, blk_stats, node_tests, point_tests);
 }
 
 // after the unions: point every core at its root and flag roots for the ranking scan
@@ -322,22 +369,29 @@ __global__ void __launch_bounds__(kDbBlock) db_flatten_kernel(DbArgs a, int32_t 
 }
 
 __global__ void __launch_bounds__(kDbBlock) db_label_kernel(DbArgs a) {
+  __shared__ unsigned long long blk_stats[2];
+  if (threadIdx.x < 2) blk_stats[threadIdx.x] = 0ull;
+  __syncthreads();
+  uint32_t node_tests = 0, point_tests = 0;
   const int32_t t = blockIdx.x * kDbBlock + threadIdx.x;
-  if (t >= a.bvh.n) return;
-  const LbvhPoint q = a.bvh.points[t];
-  const int32_t row = a.bvh.prim_id[t];
-  int32_t root = -1;
-  if (a.core_sorted[t]) {
-    root = uf_find(a.parent, row);
-  } else {
-    for_each_core_group(
-        a, q, -1, [](int32_t) { return false; },
-        [&](int32_t other) {
-          const int32_t r = uf_find(a.parent, other);
-          if (root < 0 || r < root) root = r;
-        });
+  if (t < a.bvh.n) {
+    const LbvhPoint q = a.bvh.points[t];
+    const int32_t row = a.bvh.prim_id[t];
+    int32_t root = -1;
+    if (a.core_sorted[t]) {
+      root = uf_find(a.parent, row);
+    } else {
+      for_each_core_group(
+          a, q, -1, [](int32_t) { return false; },
+          [&](int32_t other) {
+            const int32_t r = uf_find(a.parent, other);
+            if (root < 0 || r < root) root = r;
+          },
+          node_tests, point_tests);
+    }
+    a.labels[row] = root < 0 ? -1 : a.rank[root];
   }
-  a.labels[row] = root < 0 ? -1 : a.rank[root];
+  db_add_stats(a.stats + 4, blk_stats, node_tests, point_tests);
 }
 
 // tknnDbscanAssign: the caller has decided the label of every core point (>= 0; < 0: not core); a
@@ -347,21 +401,28 @@ __global__ void __launch_bounds__(kDbBlock) db_core_from_labels_kernel(DbArgs a,
   if (t < a.bvh.n) a.core_sorted[t] = core_label[a.bvh.prim_id[t]] >= 0;
 }
 __global__ void __launch_bounds__(kDbBlock) db_assign_kernel(DbArgs a, const int32_t *core_label) {
+  __shared__ unsigned long long blk_stats[2];
+  if (threadIdx.x < 2) blk_stats[threadIdx.x] = 0ull;
+  __syncthreads();
+  uint32_t node_tests = 0, point_tests = 0;
   const int32_t t = blockIdx.x * kDbBlock + threadIdx.x;
-  if (t >= a.bvh.n) return;
-  const LbvhPoint q = a.bvh.points[t];
-  const int32_t row = a.bvh.prim_id[t];
-  int32_t best = core_label[row];
-  if (best < 0) {
-    best = -1;
-    for_each_core_group(
-        a, q, -1, [](int32_t) { return false; },
-        [&](int32_t other) {
-          const int32_t l = core_label[other];  // a tight node's core points share one label: its first stands for all
-          if (best < 0 || l < best) best = l;
-        });
+  if (t < a.bvh.n) {
+    const LbvhPoint q = a.bvh.points[t];
+    const int32_t row = a.bvh.prim_id[t];
+    int32_t best = core_label[row];
+    if (best < 0) {
+      best = -1;
+      for_each_core_group(
+          a, q, -1, [](int32_t) { return false; },
+          [&](int32_t other) {
+            const int32_t l = core_label[other];  // a tight node's core points share one label: its first stands for all
+            if (best < 0 || l < best) best = l;
+          },
+          node_tests, point_tests);
+    }
+    a.labels[row] = best;
   }
-  a.labels[row] = best;
+  db_add_stats(a.stats + 4, blk_stats, node_tests, point_tests);
 }
 
 }  // namespace
@@ -399,6 +460,8 @@ void Engine::dbscan(float eps, int min_pts, int32_t *d_labels, uint8_t *d_core, 
   a.counts = d_counts;
   a.labels = d_labels;
   const unsigned blocks = (unsigned)((n + kDbBlock - 1) / kDbBlock);
+  a.stats = counters_;  // [0..5]: node / point tests of the three traversal kernels
+  OWLMI_HIP(hipMemsetAsync(counters_, 0, 6 * sizeof(unsigned long long), s));
   hipEvent_t e0 = ev_a_, e1 = ev_b_;
   OWLMI_HIP(hipEventRecord(e0, s));
   if (core_label) {
@@ -406,6 +469,7 @@ void Engine::dbscan(float eps, int min_pts, int32_t *d_labels, uint8_t *d_core, 
   } else {
     hipLaunchKernelGGL(db_core_kernel, dim3(blocks), dim3(kDbBlock), 0, s, a);
   }
+  OWLMI_HIP(hipEventRecord(ev_c_, s));  // end of the core-flag traversal
   {
     // next_core: flags -> exclusive sum (rank of a slot among the core slots) -> slot of the r-th core
     // point -> first core slot at or after each slot.  is_root / rank are free until the unions are done.
@@ -422,21 +486,32 @@ void Engine::dbscan(float eps, int min_pts, int32_t *d_labels, uint8_t *d_core, 
     OWLMI_HIP(hipGetLastError());
     OWLMI_HIP(hipEventRecord(e1, s));
     OWLMI_HIP(hipStreamSynchronize(s));
+    OWLMI_HIP(hipMemcpyAsync(h_counters_, counters_, 6 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+    OWLMI_HIP(hipStreamSynchronize(s));
     if (info) {
       float ms = 0;
       OWLMI_HIP(hipEventElapsedTime(&ms, e0, e1));
+      std::memset(info, 0, sizeof *info);
       info->clusters = -1;
       info->solve_ms = ms;
+      info->label_ms = ms;
+      info->node_tests = (int64_t)h_counters_[4];
+      info->point_tests = (int64_t)h_counters_[5];
+      info->label_point_tests = (int64_t)h_counters_[5];
     }
     return;
   }
+  OWLMI_HIP(hipEventRecord(ev_d_, s));
   hipLaunchKernelGGL(db_union_kernel, dim3(blocks), dim3(kDbBlock), 0, s, a);
+  OWLMI_HIP(hipEventRecord(ev_e_, s));
   hipLaunchKernelGGL(db_flatten_kernel, dim3(blocks), dim3(kDbBlock), 0, s, a, is_root);
   OWLMI_HIP(hipGetLastError());
   OWLMI_HIP(hipcub::DeviceScan::ExclusiveSum(scan_tmp, scan_bytes, is_root, a.rank, (int)n, s));
+  OWLMI_HIP(hipEventRecord(ev_f_, s));
   hipLaunchKernelGGL(db_label_kernel, dim3(blocks), dim3(kDbBlock), 0, s, a);
   OWLMI_HIP(hipGetLastError());
   OWLMI_HIP(hipEventRecord(e1, s));
+  OWLMI_HIP(hipMemcpyAsync(h_counters_, counters_, 6 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
   // number of clusters = rank[n-1] + is_root[n-1]
   int32_t last[2] = {0, 0};
   OWLMI_HIP(hipMemcpyAsync(&last[0], a.rank + (n - 1), 4, hipMemcpyDeviceToHost, s));
@@ -444,9 +519,18 @@ void Engine::dbscan(float eps, int min_pts, int32_t *d_labels, uint8_t *d_core, 
   OWLMI_HIP(hipStreamSynchronize(s));
   if (info) {
     float ms = 0;
+    std::memset(info, 0, sizeof *info);
     OWLMI_HIP(hipEventElapsedTime(&ms, e0, e1));
     info->clusters = last[0] + last[1];
     info->solve_ms = ms;
+    OWLMI_HIP(hipEventElapsedTime(&info->core_ms, e0, ev_c_));
+    OWLMI_HIP(hipEventElapsedTime(&info->union_ms, ev_d_, ev_e_));
+    OWLMI_HIP(hipEventElapsedTime(&info->label_ms, ev_f_, e1));
+    info->node_tests = (int64_t)(h_counters_[0] + h_counters_[2] + h_counters_[4]);
+    info->point_tests = (int64_t)(h_counters_[1] + h_counters_[3] + h_counters_[5]);
+    info->core_point_tests = (int64_t)h_counters_[1];
+    info->union_point_tests = (int64_t)h_counters_[3];
+    info->label_point_tests = (int64_t)h_counters_[5];
   }
 }
 

@@ -38,6 +38,7 @@ struct SelectArgs {
   int64_t *counts;                 // npeers (count pass)
   const int64_t *offsets;          // npeers: first row of each peer's segment (write pass)
   float4 *rows;                    // write pass
+  uint8_t *boundary;               // count pass: per sorted slot, 1 if the point lies inside some peer's box
 };
 
 __global__ void __launch_bounds__(kSelBlock) block_mask_kernel(SelectArgs a) {
@@ -77,6 +78,7 @@ __global__ void __launch_bounds__(kSelBlock) point_select_kernel(SelectArgs a) {
       }
     }
   }
+  if (!WRITE && a.boundary && t < a.n) a.boundary[t] = mine != 0ull;
   for (unsigned long long m = mine; m; m &= m - 1) atomicAdd(&cnt[__builtin_ctzll(m)], 1u);
   __syncthreads();
   if (threadIdx.x < a.npeers && cnt[threadIdx.x]) {
@@ -127,7 +129,10 @@ void Engine::halo_select(const float *d_boxes, const int32_t *d_box_peer, int32_
   a.offsets = d_offsets;
   a.rows = reinterpret_cast<float4 *>(d_rows);
   const unsigned point_blocks = (unsigned)((n + kSelBlock - 1) / kSelBlock);
+  a.boundary = boundary_;
   if (!d_rows) {
+    boundary_valid_ = true;  // (the marks are those of THESE boxes: a point inside a peer's widened cell box is a query
+                             // that peer's points can reach, and only such a query -- the halo relation is symmetric)
     OWLMI_HIP(hipMemsetAsync(d_counts, 0, (size_t)npeers * sizeof(int64_t), s));
     hipLaunchKernelGGL(block_mask_kernel, dim3((a.nblocks + kSelBlock - 1) / kSelBlock), dim3(kSelBlock), 0, s, a);
     hipLaunchKernelGGL(point_select_kernel<false>, dim3(point_blocks), dim3(kSelBlock), 0, s, a);

@@ -275,6 +275,9 @@ Engine::Engine() {
   OWLMI_HIP(hipEventCreate(&ev_a_));
   OWLMI_HIP(hipEventCreate(&ev_b_));
   OWLMI_HIP(hipEventCreate(&ev_c_));
+  OWLMI_HIP(hipEventCreate(&ev_d_));
+  OWLMI_HIP(hipEventCreate(&ev_e_));
+  OWLMI_HIP(hipEventCreate(&ev_f_));
   OWLMI_HIP(hipMalloc((void **)&counters_, kCounters * sizeof(unsigned long long)));  // [16..23]: the team kernel's per-XCD packet counters; [32]: tie rows
   OWLMI_HIP(hipMalloc((void **)&tie_list_, kTieListCap * sizeof(int32_t)));
   OWLMI_HIP(hipHostMalloc((void **)&h_counters_, 16 * sizeof(unsigned long long)));
@@ -290,6 +293,7 @@ Engine::~Engine() {
   if (isect_sorted_) (void)hipFree(isect_sorted_);
   if (next_level_) (void)hipFree(next_level_);
   if (tie_) (void)hipFree(tie_);
+  if (boundary_) (void)hipFree(boundary_);
   if (tie_list_) (void)hipFree(tie_list_);
   if (counters_) (void)hipFree(counters_);
   if (halo_mask_) (void)hipFree(halo_mask_);
@@ -299,6 +303,9 @@ Engine::~Engine() {
   if (ev_a_) (void)hipEventDestroy(ev_a_);
   if (ev_b_) (void)hipEventDestroy(ev_b_);
   if (ev_c_) (void)hipEventDestroy(ev_c_);
+  if (ev_d_) (void)hipEventDestroy(ev_d_);
+  if (ev_e_) (void)hipEventDestroy(ev_e_);
+  if (ev_f_) (void)hipEventDestroy(ev_f_);
 }
 
 void Engine::set_halo(const float *d_xyz, const int32_t *d_ids, int64_t m, hipStream_t s) {
@@ -309,7 +316,7 @@ void Engine::set_halo(const float *d_xyz, const int32_t *d_ids, int64_t m, hipSt
 }
 
 LbvhView Engine::halo_view() const {
-  if (halo_n_ > 0) return halo_.view();
+  if (halo_count() > 0) return halo_.view();
   LbvhView v;
   std::memset(&v, 0, sizeof v);
   v.root = LBVH_END;
@@ -319,6 +326,7 @@ LbvhView Engine::halo_view() const {
 void Engine::build(const float *d_xyz, const int32_t *d_ids, int64_t n, tknnBuildInfo *info, hipStream_t s) {
   OWLMI_HIP(hipEventRecord(ev_a_, s));
   halo_n_ = 0;
+  boundary_valid_ = false;
   // Per-slot solve state first: if one of these allocations fails (a 100 M-point rebuild on a full
   // card) the engine must not be left "built" with null state arrays behind a stale capacity.
   if (n > state_cap_) {
@@ -327,6 +335,8 @@ void Engine::build(const float *d_xyz, const int32_t *d_ids, int64_t n, tknnBuil
     if (isect_sorted_) (void)hipFree(isect_sorted_);
     if (next_level_) (void)hipFree(next_level_);
     if (tie_) (void)hipFree(tie_);
+    if (boundary_) (void)hipFree(boundary_);
+    boundary_ = nullptr;
     tie_ = nullptr;
     done_ = nullptr;
     isect_sorted_ = nullptr;
@@ -336,6 +346,7 @@ void Engine::build(const float *d_xyz, const int32_t *d_ids, int64_t n, tknnBuil
       OWLMI_HIP(hipMalloc((void **)&isect_sorted_, (size_t)n * sizeof(int64_t)));
       OWLMI_HIP(hipMalloc((void **)&next_level_, (size_t)n * sizeof(int32_t)));
       OWLMI_HIP(hipMalloc((void **)&tie_, (size_t)n));
+      OWLMI_HIP(hipMalloc((void **)&boundary_, (size_t)n));
     } catch (...) {
       bvh_.clear();  // unbuilt: tknnSolve then answers TKNN_E_STATE instead of launching on null arrays
       throw;
@@ -520,6 +531,17 @@ void Engine::solve(const SolveArgs &sa, int kernel, tknnSolveInfo *info, hipStre
   // Rows whose order depends on how bit-identical fp32 distances are ordered: every kernel lists by
   // (dist, index) and flags them in tie_; fix_ties redoes them in the reference's order, by the round in
   // which each neighbour was first a candidate (deviceCode.cu:77-85 -- lists persist over rounds).
+  if (sa.phase != 0) {
+    if (kernel != TKNN_KERNEL_TEAM || bvh_.size() >= (1ll << 28))
+      throw ArgError{TKNN_E_UNSUPPORTED, "tknnSolveEx: phases (interior / boundary queries) are served by the team kernels only"};
+    if (!boundary_valid_)
+      throw ArgError{TKNN_E_STATE, "tknnSolveEx: phase 1 / 2 need a tknnHaloSelect count pass since the last build (it marks the boundary queries)"};
+  }
+  struct HaloOff {  // phase 1 runs beside tknnSetHalo: it must not look at the halo tree
+    bool &flag;
+    explicit HaloOff(bool &f, bool on) : flag(f) { flag = on; }
+    ~HaloOff() { flag = false; }
+  } halo_off(ignore_halo_, sa.phase == 1);
   tknnSolveInfo mine;
   std::memset(&mine, 0, sizeof mine);
   bool solved = false;
@@ -711,6 +733,8 @@ int tknnSolveEx(tknnEngine e, const tknnSolveOptions *options, tknnSolveInfo *in
     sa.d_fb = d_fb;
     sa.d_levels = options->d_levels;
     sa.allow_unfinished = options->allow_unfinished != 0;
+    sa.phase = options->phase;
+    if (sa.phase < 0 || sa.phase > 2) throw owlmi::ArgError{TKNN_E_ARG, "tknnSolveEx: phase must be 0 (all), 1 (interior) or 2 (boundary)"};
     if (info) std::memset(info, 0, sizeof(*info));
     e->impl.solve(sa, kernel, info, (hipStream_t)stream);
   });

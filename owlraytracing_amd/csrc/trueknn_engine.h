@@ -27,6 +27,7 @@ struct SolveArgs {
   tknnNeigh *d_fb = nullptr;
   int32_t *d_levels = nullptr;
   bool allow_unfinished = false;
+  int phase = 0;  // tknnSolveOptions.phase: 0 every query, 1 interior queries in the own tree only, 2 boundary queries
 };
 
 // smallest register-list capacity instantiated for k, or -1
@@ -82,6 +83,12 @@ class Engine {
   Lbvh bvh_;
   Lbvh halo_;
   int64_t halo_n_ = 0;
+  // A phase-1 solve (queries no halo point can reach) runs beside the halo exchange: tknnSetHalo may rebuild
+  // halo_ on another host thread meanwhile, so that solve never looks at it.
+  bool ignore_halo_ = false;
+  int64_t halo_count() const { return ignore_halo_ ? 0 : halo_n_; }
+  uint8_t *boundary_ = nullptr;  // per sorted slot: 1 if the last tknnHaloSelect count pass found the point inside a peer's box
+  bool boundary_valid_ = false;
   uint8_t *done_ = nullptr;
   int64_t *isect_sorted_ = nullptr;
   int32_t *next_level_ = nullptr;
@@ -97,7 +104,7 @@ class Engine {
   int64_t slot_list_cap_ = 0;
   unsigned long long *halo_mask_ = nullptr;  // per leaf block: peers it may have points for (+ 64 cursors)
   int64_t halo_mask_cap_ = 0;
-  hipEvent_t ev_a_ = nullptr, ev_b_ = nullptr, ev_c_ = nullptr;
+  hipEvent_t ev_a_ = nullptr, ev_b_ = nullptr, ev_c_ = nullptr, ev_d_ = nullptr, ev_e_ = nullptr, ev_f_ = nullptr;
   // the packet kernel's solve launches the tie pass behind itself, before its one host round trip: set if
   // that launch has seen every flagged row (no tail ran, the list held them all)
   bool ties_early_ = false;

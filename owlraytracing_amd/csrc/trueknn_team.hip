@@ -121,6 +121,8 @@ struct TeamArgs {
   // the list (entry k: the best candidate left out); tie_fix_kernel redoes them in the reference's tie order
   uint8_t *tie;
   int32_t *tie_list;
+  const uint8_t *skip;  // per sorted slot, or null: queries with skip[slot] == skip_is sit this solve out (tknnSolveOptions.phase)
+  int32_t skip_is;
   const int32_t *slot_count;  // tie_fix_kernel, nslots == -2: length of `slots` as hipCUB's select wrote it (device side)
   // [0] (unused here) [16..23] per-XCD packet counters [1] max levels [2] node tests [3] point tests [4] sum isect
   // [5] error flags (1 max_rounds) [6] sum levels [7] unfinished [8] handed over [9] min hand-over level
@@ -735,6 +737,10 @@ __global__ void __launch_bounds__(kTeamBlock) __attribute__((amdgpu_waves_per_eu
 
     const int32_t slot = g * 64 + lane;
     bool active = slot < a.bvh.n;
+    if (a.skip) {
+      if (active && (int32_t)a.skip[slot] == a.skip_is) active = false;
+      if (__ballot(active) == 0ull) continue;  // a packet without a query of this phase
+    }
     LbvhPoint q = {0.f, 0.f, 0.f, -1};
     if (active) q = a.bvh.points[slot];
     const int32_t row = active ? a.bvh.prim_id[slot] : 0;
@@ -1638,7 +1644,7 @@ void Engine::launch_tie_fix(const SolveArgs &sa, const int32_t *slots, int32_t n
   a.bvh = bvh_.view();
   a.halo = halo_view();
   a.wide[0] = bvh_.wide_view();
-  if (halo_n_ > 0) a.wide[1] = halo_.wide_view();
+  if (halo_count() > 0) a.wide[1] = halo_.wide_view();
   a.start_radius = sa.start_radius;
   a.k = sa.k;
   a.out_idx = sa.d_idx;
@@ -1651,7 +1657,7 @@ void Engine::launch_tie_fix(const SolveArgs &sa, const int32_t *slots, int32_t n
   using FixEntry = void (*)(TeamArgs, const int32_t *, int32_t);
   static const FixEntry entries[2][3] = {{tie_fix_kernel<false, 1>, tie_fix_kernel<false, 2>, tie_fix_kernel<false, 4>},
                                          {tie_fix_kernel<true, 1>, tie_fix_kernel<true, 2>, tie_fix_kernel<true, 4>}};
-  const FixEntry entry = entries[halo_n_ > 0 ? 1 : 0][sa.k <= 16 ? 0 : (sa.k <= 32 ? 1 : 2)];
+  const FixEntry entry = entries[halo_count() > 0 ? 1 : 0][sa.k <= 16 ? 0 : (sa.k <= 32 ? 1 : 2)];
   void *kargs[] = {(void *)&a, (void *)&slots, (void *)&nslots};
   OWLMI_HIP(hipLaunchKernel((const void *)entry, dim3(blocks), dim3(kTeamBlock), kargs, 0, s));
 }
@@ -1746,7 +1752,7 @@ bool Engine::solve_team(const SolveArgs &sa, tknnSolveInfo *info, hipStream_t s)
   a.bvh = bvh_.view();
   a.halo = halo_view();
   a.wide[0] = bvh_.wide_view();
-  if (halo_n_ > 0)
+  if (halo_count() > 0)
     a.wide[1] = halo_.wide_view();
   else
     std::memset(&a.wide[1], 0, sizeof(a.wide[1]));
@@ -1760,7 +1766,7 @@ bool Engine::solve_team(const SolveArgs &sa, tknnSolveInfo *info, hipStream_t s)
     // a halo tree may hold anything
     int dims = 0;
     for (int ax = 0; ax < 3; ax++) dims += scene_[3 + ax] > scene_[ax] ? 1 : 0;
-    if (halo_n_ > 0) dims = 3;
+    if (halo_count() > 0) dims = 3;
     a.tie_span = dims >= 3 ? 1.73206f : (dims == 2 ? 1.41422f : 1.00001f);
   }
   a.diag = 0;
@@ -1776,6 +1782,8 @@ bool Engine::solve_team(const SolveArgs &sa, tknnSolveInfo *info, hipStream_t s)
   a.tie = tie_;
   a.tie_list = tie_list_;
   a.slot_count = nullptr;
+  a.skip = sa.phase ? boundary_ : nullptr;
+  a.skip_is = sa.phase == 1 ? 1 : 0;
   a.isect_sorted = isect_sorted_;
   a.next_level = next_level_;
   a.counters = counters_;
@@ -1784,7 +1792,7 @@ bool Engine::solve_team(const SolveArgs &sa, tknnSolveInfo *info, hipStream_t s)
   OWLMI_HIP(hipGetDeviceProperties(&prop, device_));
   int per_cu = 2;
   const size_t lds = (size_t)kTeamBlock / 64 * kTeamLds;
-  const bool with_halo = halo_n_ > 0;
+  const bool with_halo = halo_count() > 0;
   const int nreg = sa.k <= 16 ? 1 : (sa.k <= 32 ? 2 : 4);  // list registers per lane
   const int nreg_at = nreg == 4 ? 2 : nreg - 1;           // index into the tables of instantiations
   const char *walk_all = getenv("TKNN_TEAM_WALK_ALL");    // measurements only: k > 32 without the packet kernel
@@ -1858,7 +1866,8 @@ bool Engine::solve_team(const SolveArgs &sa, tknnSolveInfo *info, hipStream_t s)
 
   // one launch instead of six fills (each costs a few microseconds of its own on the stream): done = 1,
   // tie = 0, all counters 0 except [9] (min hand-over level) = ~0, levels = -1
-  hipLaunchKernelGGL(team_prep_kernel, dim3(prop.multiProcessorCount * 4), dim3(256), 0, s, done_, tie_, n, counters_, sa.d_levels);
+  // (phase 2 completes the rows and levels a phase-1 call has begun: levels are preset once, by phase 0 or 1)
+  hipLaunchKernelGGL(team_prep_kernel, dim3(prop.multiProcessorCount * 4), dim3(256), 0, s, done_, tie_, n, counters_, sa.phase == 2 ? nullptr : sa.d_levels);
   OWLMI_HIP(hipEventRecord(ev_a_, s));
   {
     void *kargs[] = {(void *)&a};

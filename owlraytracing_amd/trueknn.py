@@ -118,10 +118,15 @@ class TrueKNN:
                                                     ctypes.c_void_p(rows.data_ptr()), self._stream()))
             return rows, host_counts.tolist()
 
+    supports_phases = True  # solve(phase=1 | 2): interior / boundary queries of a tile (tknnSolveOptions.phase)
+
     def solve(self, k, start_radius, kernel=_lib.KERNEL_AUTO, max_rounds=64, want_fb=False,
-              out=None, want_levels=False, allow_unfinished=False):
+              out=None, want_levels=False, allow_unfinished=False, phase=0, stream=None):
         """Returns dict(idx (n,k) int32, dist (n,k) f32, intersections (n,) int64[, fb (n*k*24,) uint8])
-        as CUDA tensors plus ``info``.  ``out`` may carry preallocated tensors of those names."""
+        as CUDA tensors plus ``info``.  ``out`` may carry preallocated tensors of those names.
+        ``phase`` 1 / 2: only the interior / boundary queries marked by the last ``halo_select`` (sharded use);
+        ``stream``: a torch.cuda.Stream to launch on instead of the current one (a phase-1 solve runs on a
+        stream and host thread of its own beside the halo exchange)."""
         torch = self._torch
         n = self.n
         out = dict(out or {})
@@ -143,11 +148,13 @@ class TrueKNN:
             opt = _lib.SolveOptions()
             opt.k, opt.start_radius, opt.kernel = int(k), float(start_radius), int(kernel)
             opt.max_rounds, opt.allow_unfinished = int(max_rounds), int(bool(allow_unfinished))
+            opt.phase = int(phase)
             for field, name in (("d_idx", "idx"), ("d_dist", "dist"), ("d_intersections", "intersections"),
                                 ("d_fb", "fb"), ("d_levels", "levels")):
                 p = ptr(name)
                 setattr(opt, field, p.value if p is not None else None)
-            _lib.check(self._lib.tknnSolveEx(self._h, ctypes.byref(opt), ctypes.byref(info), self._stream()))
+            launch_on = self._stream() if stream is None else ctypes.c_void_p(stream.cuda_stream)
+            _lib.check(self._lib.tknnSolveEx(self._h, ctypes.byref(opt), ctypes.byref(info), launch_on))
         self.last_info = info.as_dict()
         out["info"] = self.last_info
         return out

@@ -77,6 +77,8 @@ class CheckerEngine:
 
 
 def make_points(name, n):
+    if name == "counter":  # bench.py's set: defined independently of how it is cut (datasets.uniform3d_counter)
+        return datasets.uniform3d_counter(0, n, seed=0)
     if name == "uniform":
         return datasets.uniform3d(n, seed=5)
     if name == "clustered":
@@ -97,7 +99,10 @@ def main():
     pts = make_points(name, n)
     lo, hi = n * rank // world, n * (rank + 1) // world  # arbitrary initial ownership: contiguous slices
     solver = tkd.ShardedTrueKNN(dev, engine_factory=None if use_gpu else CheckerEngine, halo_levels=int(os.environ.get("HALO_LEVELS", "1")))
-    solver.load_points(torch.from_numpy(pts[lo:hi]), torch.arange(lo, hi, dtype=torch.int32))
+    if name == "counter":
+        solver.load_counter_based(n, seed=0)  # what `bench.py --gpus N --scaling strong` does: every rank draws its slice
+    else:
+        solver.load_points(torch.from_numpy(pts[lo:hi]), torch.arange(lo, hi, dtype=torch.int32))
     if os.environ.get("DBSCAN_EPS"):
         r = solver.dbscan(float(os.environ["DBSCAN_EPS"]), int(os.environ.get("DBSCAN_MINPTS", "4")))
         rows = torch.cat([solver.ids.view(-1, 1).double().cpu(), r["labels"].view(-1, 1).double().cpu(),

@@ -149,3 +149,71 @@ def test_hip_dbscan_rows_not_ids_and_the_assign_step():
                 want = core_label[p] if want < 0 else min(want, core_label[p])
         assert out[q] == want
     eng.close()
+
+
+def test_threaded_spec_equals_the_serial_spec():
+    """oracle.dbscan_threaded (bench.py's CPU baseline: same grid and arithmetic, lock-free unions on all cores)
+    against the serial statement of the spec, label for label."""
+    for name, xyz, eps, min_pts in _cases():
+        eps32 = float(np.float32(eps))
+        a, b = oracle.dbscan(xyz, eps32, min_pts), oracle.dbscan_threaded(xyz, eps32, min_pts)
+        assert np.array_equal(a["labels"], b["labels"]) and np.array_equal(a["core"], b["core"]) and a["clusters"] == b["clusters"], name
+    xyz = datasets.gaussian_mixture3d(120_000, components=64, sigma=0.02, seed=1)
+    a, b = oracle.dbscan(xyz, float(np.float32(0.01)), 4), oracle.dbscan_threaded(xyz, float(np.float32(0.01)), 4)
+    assert np.array_equal(a["labels"], b["labels"]) and np.array_equal(a["core"], b["core"])
+
+
+@pytest.mark.gpu
+def test_config3_full_size():
+    """BASELINE config 3 at its full size -- 10 M Gaussian-mixture points, eps 0.01, minPts 4 (about 5 000
+    neighbours per point: the tight-node path that the scaled-down sets never stress):
+      * cluster count at 1 M points of the same mixture equals a single run of the serial spec;
+      * at 10 M, core flags and labels of 2 500 sampled points recomputed from their eps-balls (KD-tree over
+        all points, fp32 distance arithmetic of the spec): core <=> |N(p)| >= minPts; a core point shares its
+        label with every core point in its ball; a border point carries the smallest label among the core points
+        in its ball; a point with no core point in its ball is noise;
+      * labels of all 10 M points equal the threaded CPU spec's (oracle.dbscan_threaded), as do the core flags."""
+    import torch
+    from scipy.spatial import cKDTree
+
+    from owlraytracing_amd.trueknn import TrueKNN
+    eps, min_pts = float(np.float32(0.01)), 4
+    eng = TrueKNN()
+    # 1 M: the whole spec, serially
+    small = datasets.gaussian_mixture3d(1_000_000, components=64, sigma=0.02, seed=1)
+    eng.build(small)
+    got = eng.dbscan(eps, min_pts)
+    ref = oracle.dbscan_threaded(small, eps, min_pts)
+    assert got["info"]["clusters"] == ref["clusters"]
+    assert np.array_equal(got["labels"].cpu().numpy(), ref["labels"])
+    # 10 M
+    n = 10_000_000
+    xyz = datasets.gaussian_mixture3d(n, components=64, sigma=0.02, seed=1)
+    eng.build(torch.from_numpy(xyz).cuda())
+    got = eng.dbscan(eps, min_pts)
+    info = got["info"]
+    lab, core = got["labels"].cpu().numpy(), got["core"].cpu().numpy()
+    assert info["clusters"] == int(lab.max()) + 1 and info["point_tests"] > 0 and info["union_ms"] > 0
+    assert np.all(lab[core] >= 0)
+    tree = cKDTree(xyz)  # float32 data: queries below re-test every returned pair with the spec's arithmetic
+    rng = np.random.default_rng(33)
+    sample = rng.choice(n, 2500, replace=False)
+    balls = tree.query_ball_point(xyz[sample].astype(np.float64), eps * 1.0001, workers=-1)
+    for q, ball in zip(sample, balls):
+        ball = np.asarray(ball)
+        d = xyz[ball] - xyz[q]
+        dist = np.sqrt((d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]) + d[:, 2] * d[:, 2], dtype=np.float32)
+        near = ball[dist <= np.float32(eps)]
+        assert bool(core[q]) == (len(near) >= min_pts), q  # q itself is in `near`
+        near_core = near[core[near]]
+        if core[q]:
+            assert np.all(lab[near_core] == lab[q]), q
+        elif len(near_core):
+            assert lab[q] == lab[near_core].min(), q
+        else:
+            assert lab[q] == -1, q
+    full = oracle.dbscan_threaded(xyz, eps, min_pts)
+    assert full["clusters"] == info["clusters"]
+    assert np.array_equal(core, full["core"])
+    assert np.array_equal(lab, full["labels"])
+    eng.close()

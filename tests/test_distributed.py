@@ -62,6 +62,15 @@ def test_tiles_and_halo_exchange_reproduce_the_single_process_result(tmp_path, w
     assert int(got["halo_points"]) > 0
 
 
+@pytest.mark.parametrize("world", [2, 3])
+def test_strong_scaling_split_of_the_counter_based_set_equals_one_rank(tmp_path, world):
+    """`bench.py --scaling strong`: ONE point set (counter-based generator, the same points whatever the number of
+    ranks) cut into `world` Morton tiles; rows, intersection counts and rounds equal the single-process result."""
+    n, k = 2 * 1024 + 77, 4  # crosses nothing special; datasets.CHUNK-sized sets are the GPU-side runs
+    got = _run("checker", world, n, k, "counter", tmp_path, 29680 + world)
+    _check(got, "counter", n, k)
+
+
 def test_stragglers_force_a_wider_halo(tmp_path):
     # a start radius far too small: the first halo (1 level) cannot serve the final radius level
     got = _run("checker", 2, 1500, 6, "uniform", tmp_path, 29631, {"START_RADIUS": "0.004", "HALO_LEVELS": "1"})
@@ -76,6 +85,17 @@ def test_two_ranks_sharing_one_gpu_with_the_hip_engine(tmp_path):
     n, k = 200_000, 10
     got = _run("hip", 2, n, k, "uniform", tmp_path, 29641, {"HALO_LEVELS": "2"})
     _check(got, "uniform", n, k)
+
+
+@pytest.mark.gpu
+def test_interior_and_boundary_phases_reproduce_the_single_process_result(tmp_path):
+    """TKNN_SHARD_OVERLAP=1: interior queries solved in the own tree on a side stream and host thread while the halo
+    travels, boundary queries afterwards with own + halo tree (tknnSolveOptions.phase 1 / 2): the same rows."""
+    n, k = 300_000, 10
+    got = _run("hip", 3, n, k, "uniform", tmp_path, 29645, {"HALO_LEVELS": "2", "TKNN_SHARD_OVERLAP": "1"})
+    _check(got, "uniform", n, k)
+    got = _run("hip", 2, 120_000, 6, "clustered", tmp_path, 29646, {"HALO_LEVELS": "1", "TKNN_SHARD_OVERLAP": "1", "START_RADIUS": "0.002"})
+    _check(got, "clustered", 120_000, 6, r0=0.002)
 
 
 @pytest.mark.gpu
