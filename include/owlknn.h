@@ -206,6 +206,24 @@ TKNN_API int tknnDbscan(tknnEngine e, float eps, int min_pts, int32_t *d_labels,
 TKNN_API int tknnDbscanAssign(tknnEngine e, float eps, const int32_t *d_core_label, int32_t *d_labels,
                               tknnDbscanInfo *info, void *stream);
 
+/* ---- RT-DBSCAN with an auto-grown eps (BASELINE.json configs[4]) ----------------------------------------------
+ * No counterpart in the reference (it has no RT-DBSCAN source; BASELINE.md section 4: "spec TBD"), so the rule is this
+ * build's own spec (oracle/dbscan_oracle.c, dbref_dbscan_auto), built on the reference's one growth rule, the radius
+ * doubling of samples/s01-trueknn/hostCode.cpp:310-330: eps starts at eps0 and doubles (fp32) until at most
+ * floor(max_noise * n) points are noise; the labelling returned is tknnDbscan's at that eps.  Growth rounds only
+ * count noise (core flags are kept from round to round: neighbourhoods only grow), one full clustering follows.
+ * TKNN_E_ROUNDS if max_rounds rounds do not get there (labels then hold the last round's). */
+typedef struct {
+  tknnDbscanInfo last; /* the full clustering at the final eps */
+  int32_t rounds;      /* growth rounds run (1 = eps0 was enough) */
+  float eps;           /* the final eps = eps0 * 2^(rounds-1) */
+  int64_t noise;       /* points labelled -1 at the final eps */
+  float probe_ms;      /* all growth rounds (HIP events) */
+  int32_t pad_;
+} tknnDbscanAutoInfo;
+TKNN_API int tknnDbscanAuto(tknnEngine e, float eps0, int min_pts, double max_noise, int max_rounds, int32_t *d_labels,
+                            uint8_t *d_core, tknnDbscanAutoInfo *info, void *stream);
+
 /* Test / debug export of the tree to host memory (any pointer may be NULL):
  *   nodes      (n-1) x 8 dwords {lo[3], split, hi[3], other}   (include/owl/lbvh_device.h)
  *   rope_node  n-1, rope_leaf n, prim_id n (caller index of sorted slot)            */

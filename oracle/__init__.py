@@ -15,6 +15,7 @@ from .loader import (  # noqa: F401
     bruteforce_knn,
     build,
     dbscan,
+    dbscan_auto,
     dbscan_threaded,
     distance,
     num_threads,

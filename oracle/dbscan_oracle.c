@@ -330,3 +330,41 @@ int dbref_dbscan_mt(const float *xyz, int64_t n, float eps, int min_pts, int32_t
   free(g.items);
   return nclusters;
 }
+
+
+/* ---- "eps auto-grown" (BASELINE.json configs[4]) ---------------------------------------------------------------
+ * The reference has nothing of the kind (no RT-DBSCAN source at all, and BASELINE.md section 4 marks the
+ * rule "spec TBD"), so this, too, is a SPEC written for this build.  It is built on the one growth rule the reference
+ * has, the radius doubling of its round loop (samples/s01-trueknn/hostCode.cpp:310-330: while some query is
+ * unfinished, radius *= 2 and go again), carried over from "a query without k neighbours" to "a point without a
+ * cluster":
+ *
+ *   eps_0 = the given start value (> 0; the start-radius sampler of owlraytracing_amd/radius.py supplies one);
+ *   round t: DBSCAN(eps_t, minPts) as specified above; noise_t = number of points labelled -1;
+ *   finished at the first t with  noise_t <= floor(max_noise * n)  (max_noise in [0, 1]); else eps_{t+1} = eps_t * 2
+ *   in fp32 (hostCode.cpp:321) and another round -- at most max_rounds rounds, like the reference's loop a global
+ *   value: one eps for all points.
+ *   Result: the labelling of the final round, its eps and the number of rounds run.
+ *
+ * Facts an implementation may use (both follow from N_eps(p) growing with eps): a core point stays core, and a point
+ * that is not noise stays not noise, so noise_t never grows and only the final round needs clusters.
+ * Returns the number of clusters of the final round; < 0: bad arguments / out of memory; -3: max_rounds exhausted
+ * (labels then hold the last round's). */
+int dbref_dbscan_auto(const float *xyz, int64_t n, float eps0, int min_pts, double max_noise, int max_rounds,
+                      int32_t *labels, uint8_t *core, float *eps_final, int *rounds, int64_t *noise_final) {
+  if (!xyz || !labels || !core || n <= 0 || !(eps0 > 0) || min_pts < 1 || !(max_noise >= 0) || !(max_noise <= 1) || max_rounds < 1) return -1;
+  const int64_t bound = (int64_t)floor(max_noise * (double)n);
+  float eps = eps0;
+  for (int t = 0; t < max_rounds; t++) {
+    int rc = dbref_dbscan_mt(xyz, n, eps, min_pts, labels, core, NULL);
+    if (rc < 0) return rc;
+    int64_t noise = 0;
+    for (int64_t i = 0; i < n; i++) noise += labels[i] < 0;
+    if (eps_final) *eps_final = eps;
+    if (rounds) *rounds = t + 1;
+    if (noise_final) *noise_final = noise;
+    if (noise <= bound) return rc;
+    eps = eps * 2.0f; /* hostCode.cpp:321 */
+  }
+  return -3;
+}

@@ -65,6 +65,10 @@ def _load():
         lib.dbref_dbscan_mt.restype = ctypes.c_int
         lib.dbref_dbscan_mt.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_float, ctypes.c_int,
                                         ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+        lib.dbref_dbscan_auto.restype = ctypes.c_int
+        lib.dbref_dbscan_auto.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_float, ctypes.c_int, ctypes.c_double,
+                                          ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                          ctypes.c_void_p]
         assert lib.tkref_sizeof_neigh() == NEIGH_DTYPE.itemsize
         _lib = lib
     return _lib
@@ -174,4 +178,23 @@ def dbscan_threaded(xyz, eps, min_pts):
     if rc < 0:
         raise OracleError("threaded dbscan failed: %d" % rc)
     return {"labels": labels, "core": core.astype(bool), "clusters": rc, "seconds": seconds}
+
+
+def dbscan_auto(xyz, eps0, min_pts, max_noise=0.05, max_rounds=32):
+    """The "eps auto-grown" spec of oracle/dbscan_oracle.c (dbref_dbscan_auto): eps doubles from eps0 until at most
+    floor(max_noise * n) points are noise.  dict(labels, core, clusters, eps, rounds, noise)."""
+    lib = _load()
+    xyz = _points(xyz)
+    n = len(xyz)
+    labels = np.empty(n, np.int32)
+    core = np.empty(n, np.uint8)
+    eps = ctypes.c_float(0)
+    rounds = ctypes.c_int(0)
+    noise = ctypes.c_int64(0)
+    rc = lib.dbref_dbscan_auto(xyz.ctypes.data, n, ctypes.c_float(eps0), int(min_pts), ctypes.c_double(max_noise), int(max_rounds),
+                               labels.ctypes.data, core.ctypes.data, ctypes.byref(eps), ctypes.byref(rounds), ctypes.byref(noise))
+    if rc < 0:
+        raise OracleError("dbscan_auto failed: %d%s" % (rc, " (max_rounds exhausted)" if rc == -3 else ""))
+    return {"labels": labels, "core": core.astype(bool), "clusters": rc, "eps": float(eps.value), "rounds": int(rounds.value),
+            "noise": int(noise.value)}
 

@@ -70,6 +70,16 @@ class DbscanInfo(ctypes.Structure):
         return {name: getattr(self, name) for name, _ in self._fields_ if name != "pad_"}
 
 
+class DbscanAutoInfo(ctypes.Structure):
+    _fields_ = [("last", DbscanInfo), ("rounds", ctypes.c_int32), ("eps", ctypes.c_float), ("noise", ctypes.c_int64),
+                ("probe_ms", ctypes.c_float), ("pad_", ctypes.c_int32)]
+
+    def as_dict(self):
+        d = {"rounds": self.rounds, "eps": self.eps, "noise": self.noise, "probe_ms": self.probe_ms}
+        d.update(self.last.as_dict())
+        return d
+
+
 class BuildInfo(ctypes.Structure):
     _fields_ = [("build_ms", ctypes.c_float), ("device_bytes", ctypes.c_int64), ("n", ctypes.c_int32)]
 
@@ -102,6 +112,8 @@ SIGNATURES = {
                                   ctypes.c_void_p, ctypes.POINTER(DbscanInfo), ctypes.c_void_p]),
     "tknnDbscanAssign": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_float, ctypes.c_void_p, ctypes.c_void_p,
                                         ctypes.POINTER(DbscanInfo), ctypes.c_void_p]),
+    "tknnDbscanAuto": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_float, ctypes.c_int, ctypes.c_double, ctypes.c_int, ctypes.c_void_p,
+                                      ctypes.c_void_p, ctypes.POINTER(DbscanAutoInfo), ctypes.c_void_p]),
     "tknnExportTree": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                                       ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     "tknnDebugThresholds": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64,

@@ -41,6 +41,7 @@ struct DbArgs {
   float eps_wide;  // eps * (1 + 1e-6): the box prefilter must not cut what the rounded sphere test accepts
   int min_pts;
   int want_counts;
+  int keep_core;         // tknnDbscanAuto: slots already flagged core by a round with a smaller eps stay core (N(p) only grows)
   uint8_t *core_sorted;  // per sorted slot
   uint8_t *core;         // per caller index (may be null)
   int32_t *counts;       // per caller index (may be null)
@@ -189,6 +190,7 @@ __device__ __forceinline__ void for_each_core_group(const DbArgs &a, const LbvhP
 
 __device__ __forceinline__ void db_core_body(const DbArgs &a, int32_t t, uint32_t &node_tests, uint32_t &point_tests) {
   const LbvhView &bvh = a.bvh;
+  if (a.keep_core && a.core_sorted[t]) return;
   const LbvhPoint q = bvh.points[t];
   int32_t cnt = 0;
   const int stop_at = a.want_counts ? 0x7fffffff : a.min_pts;
@@ -425,6 +427,66 @@ __global__ void __launch_bounds__(kDbBlock) db_assign_kernel(DbArgs a, const int
   db_add_stats(a.stats + 4, blk_stats, node_tests, point_tests);
 }
 
+// ---- "eps auto-grown" (tknnDbscanAuto; spec: oracle/dbscan_oracle.c, dbref_dbscan_auto) ----------------------------
+// A round of the growth loop only has to COUNT the noise points: is there a core point within eps of a point that is
+// not core itself?  One traversal with an early exit; a subtree without a core point (next_core) is skipped, a node
+// wholly inside the sphere that holds one settles the question.  Points found not to be noise never are again (a core
+// point stays core as eps grows), so later rounds probe the remaining noise only.
+__device__ __forceinline__ bool db_has_core_neighbour(const DbArgs &a, const LbvhPoint &q, uint32_t &node_tests, uint32_t &point_tests) {
+  const LbvhView &bvh = a.bvh;
+  const float r = a.eps_wide;
+  int32_t ref = bvh.root;
+  while (ref != LBVH_END) {
+    if (ref >= 0) {
+      const LbvhNode nd = bvh.nodes[ref];
+      node_tests++;
+      const bool hit = (nd.lo[0] - r <= q.x) & (q.x <= nd.hi[0] + r) & (nd.lo[1] - r <= q.y) & (q.y <= nd.hi[1] + r) &
+                       (nd.lo[2] - r <= q.z) & (q.z <= nd.hi[2] + r);
+      if (!hit || a.next_core[lbvh_first(ref, nd.other)] > lbvh_last(ref, nd.other)) {  // out of reach, or no core point below
+        ref = bvh.rope_node[ref];
+        continue;
+      }
+      float far2, near2;
+      box_dist2(nd, q, far2, near2);
+      if (far2 <= a.eps_in2) return true;  // all of it within eps, and a core point among it
+      if (near2 > a.eps_out2) {
+        ref = bvh.rope_node[ref];
+        continue;
+      }
+      ref = lbvh_left_ref(ref, nd);
+    } else {
+      const int32_t slot = ~ref;
+      if (a.core_sorted[slot]) {
+        const LbvhPoint p = bvh.points[slot];
+        point_tests++;
+        if (knn_sqrt(knn_dist2(p.x, p.y, p.z, q.x, q.y, q.z)) <= a.eps) return true;
+      }
+      ref = bvh.rope_leaf[slot];
+    }
+  }
+  return false;
+}
+
+// noise[slot] (per sorted slot): in, unless first_round: 1 = was noise in the round before; out: 1 = is noise now.
+// stats[0..1] += node / point tests, stats[6] += points still noise.
+__global__ void __launch_bounds__(kDbBlock) db_noise_probe_kernel(DbArgs a, uint8_t *noise, int first_round) {
+  __shared__ unsigned long long blk_stats[2], blk_noise[2];
+  if (threadIdx.x < 2) blk_stats[threadIdx.x] = blk_noise[threadIdx.x] = 0ull;
+  __syncthreads();
+  uint32_t node_tests = 0, point_tests = 0, still = 0;
+  const int32_t t = blockIdx.x * kDbBlock + threadIdx.x;
+  if (t < a.bvh.n) {
+    if (a.core_sorted[t]) {
+      noise[t] = 0;
+    } else if (first_round || noise[t]) {
+      still = db_has_core_neighbour(a, a.bvh.points[t], node_tests, point_tests) ? 0u : 1u;
+      noise[t] = (uint8_t)still;
+    }
+  }
+  db_add_stats(a.stats + 0, blk_stats, node_tests, point_tests);
+  db_add_stats(a.stats + 6, blk_noise, still, 0u);
+}
+
 }  // namespace
 
 void Engine::dbscan(float eps, int min_pts, int32_t *d_labels, uint8_t *d_core, int32_t *d_counts,
@@ -447,6 +509,7 @@ void Engine::dbscan(float eps, int min_pts, int32_t *d_labels, uint8_t *d_core, 
   a.eps_wide = eps * 1.000001f;
   a.min_pts = min_pts;
   a.want_counts = d_counts != nullptr;
+  a.keep_core = 0;
   a.parent = (int32_t *)ws;
   int32_t *is_root = (int32_t *)(ws + (size_t)n * 4);
   a.rank = (int32_t *)(ws + (size_t)n * 8);  // n + 1 entries
@@ -532,6 +595,92 @@ void Engine::dbscan(float eps, int min_pts, int32_t *d_labels, uint8_t *d_core, 
     info->union_point_tests = (int64_t)h_counters_[3];
     info->label_point_tests = (int64_t)h_counters_[5];
   }
+}
+
+
+// tknnDbscanAuto: the growth loop of the spec -- rounds of (core flags of the points not core yet, noise probe of the
+// points still noise) with eps doubling, then ONE full clustering at the eps that brought the noise under the bound.
+void Engine::dbscan_auto(float eps0, int min_pts, double max_noise, int max_rounds, int32_t *d_labels, uint8_t *d_core,
+                         tknnDbscanAutoInfo *info, hipStream_t s) {
+  const int64_t n = bvh_.size();
+  const int64_t bound = (int64_t)std::floor(max_noise * (double)n);
+  // scratch of the probe rounds: parent (unused but written by the core kernel), rank / flags, core ranks, next_core,
+  // core flags per slot, noise flags per slot
+  size_t scan_bytes = 0;
+  OWLMI_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, (int32_t *)nullptr, (int32_t *)nullptr, (int)n, s));
+  const size_t need = (((size_t)n * (4 + 4 + 4 + 4 + 1 + 1)) + 32 + 255) / 256 * 256;
+  if (need + scan_bytes > wave_ws_bytes_) {
+    if (wave_ws_) (void)hipFree(wave_ws_);
+    wave_ws_ = nullptr;
+    OWLMI_HIP(hipMalloc(&wave_ws_, need + scan_bytes));
+    wave_ws_bytes_ = need + scan_bytes;
+  }
+  char *ws = (char *)wave_ws_;
+  DbArgs a;
+  std::memset(&a, 0, sizeof a);
+  a.bvh = bvh_.view();
+  a.min_pts = min_pts;
+  a.keep_core = 1;
+  a.parent = (int32_t *)ws;
+  int32_t *core_rank = (int32_t *)(ws + (size_t)n * 4);
+  a.rank = (int32_t *)(ws + (size_t)n * 8);                     // n + 1 entries: flags, then positions
+  int32_t *next_core = (int32_t *)(ws + (size_t)n * 12 + 4);  // n + 1 entries
+  a.core_sorted = (uint8_t *)(ws + (size_t)n * 16 + 8);
+  uint8_t *noise = a.core_sorted + n;
+  a.next_core = next_core;
+  a.stats = counters_;
+  void *scan_tmp = ws + need;
+  const unsigned blocks = (unsigned)((n + kDbBlock - 1) / kDbBlock), blocks1 = (unsigned)((n + 1 + kDbBlock - 1) / kDbBlock);
+  OWLMI_HIP(hipMemsetAsync(a.core_sorted, 0, (size_t)n, s));
+  OWLMI_HIP(hipEventRecord(ev_a_, s));
+  float eps = eps0;
+  int rounds = 0;
+  int64_t noise_now = n;
+  bool reached = false;
+  for (int t = 0; t < max_rounds; t++) {
+    a.eps = eps;
+    a.eps_wide = eps * 1.000001f;
+    a.eps_in2 = eps * eps * (1.0f - 1e-5f);
+    a.eps_out2 = eps * eps * (1.0f + 1e-5f);
+    OWLMI_HIP(hipMemsetAsync(counters_, 0, 8 * sizeof(unsigned long long), s));
+    hipLaunchKernelGGL(db_core_kernel, dim3(blocks), dim3(kDbBlock), 0, s, a);
+    {
+      int32_t *flag = a.rank, *pos = a.rank;
+      hipLaunchKernelGGL(db_core_flag_kernel, dim3(blocks), dim3(kDbBlock), 0, s, a, flag);
+      OWLMI_HIP(hipcub::DeviceScan::ExclusiveSum(scan_tmp, scan_bytes, flag, core_rank, (int)n, s));
+      OWLMI_HIP(hipMemsetAsync(pos, 0x7f, ((size_t)n + 1) * sizeof(int32_t), s));
+      hipLaunchKernelGGL(db_core_pos_kernel, dim3(blocks), dim3(kDbBlock), 0, s, a, core_rank, pos);
+      hipLaunchKernelGGL(db_next_core_kernel, dim3(blocks1), dim3(kDbBlock), 0, s, a, core_rank, pos, next_core);
+    }
+    hipLaunchKernelGGL(db_noise_probe_kernel, dim3(blocks), dim3(kDbBlock), 0, s, a, noise, t == 0 ? 1 : 0);
+    OWLMI_HIP(hipGetLastError());
+    OWLMI_HIP(hipMemcpyAsync(h_counters_, counters_, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+    OWLMI_HIP(hipStreamSynchronize(s));
+    rounds = t + 1;
+    noise_now = (int64_t)h_counters_[6];
+    if (noise_now <= bound) {
+      reached = true;
+      break;
+    }
+    if (t + 1 < max_rounds) eps = eps * 2.0f;  // hostCode.cpp:321
+  }
+  OWLMI_HIP(hipEventRecord(ev_b_, s));
+  OWLMI_HIP(hipEventSynchronize(ev_b_));
+  float probe_ms = 0;
+  OWLMI_HIP(hipEventElapsedTime(&probe_ms, ev_a_, ev_b_));
+  // the clusters of the final eps (also when the rounds ran out: the caller gets the last round's labelling and an error)
+  tknnDbscanInfo last;
+  std::memset(&last, 0, sizeof last);
+  dbscan(eps, min_pts, d_labels, d_core, nullptr, &last, s);
+  if (info) {
+    std::memset(info, 0, sizeof *info);
+    info->last = last;
+    info->rounds = rounds;
+    info->eps = eps;
+    info->noise = noise_now;
+    info->probe_ms = probe_ms;
+  }
+  if (!reached) throw RoundsExceeded{};
 }
 
 }  // namespace owlmi

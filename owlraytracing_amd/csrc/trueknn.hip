@@ -783,6 +783,24 @@ int tknnDbscanAssign(tknnEngine e, float eps, const int32_t *d_core_label, int32
   });
 }
 
+int tknnDbscanAuto(tknnEngine e, float eps0, int min_pts, double max_noise, int max_rounds, int32_t *d_labels, uint8_t *d_core,
+                   tknnDbscanAutoInfo *info, void *stream) {
+  if (!e || !d_labels) {
+    g_last_error = "tknnDbscanAuto: engine or labels pointer is NULL";
+    return TKNN_E_ARG;
+  }
+  const int rc = guarded_on(e, [&] {
+    if (!e->impl.built()) throw owlmi::ArgError{TKNN_E_STATE, "tknnDbscanAuto: call tknnBuild first"};
+    if (!(eps0 > 0.f) || !std::isfinite(eps0)) throw owlmi::ArgError{TKNN_E_ARG, "tknnDbscanAuto: eps0 must be finite and > 0"};
+    if (min_pts < 1) throw owlmi::ArgError{TKNN_E_ARG, "tknnDbscanAuto: min_pts must be >= 1"};
+    if (!(max_noise >= 0.0) || !(max_noise <= 1.0)) throw owlmi::ArgError{TKNN_E_ARG, "tknnDbscanAuto: max_noise is a share of the points, 0 .. 1"};
+    if (max_rounds < 1) throw owlmi::ArgError{TKNN_E_ARG, "tknnDbscanAuto: max_rounds must be >= 1"};
+    e->impl.dbscan_auto(eps0, min_pts, max_noise, max_rounds, d_labels, d_core, info, (hipStream_t)stream);
+  });
+  if (rc == TKNN_E_ROUNDS) g_last_error = "tknnDbscanAuto: max_rounds doublings of eps did not bring the noise under the bound";
+  return rc;
+}
+
 int tknnExportTree(tknnEngine e, void *nodes, int32_t *rope_node, int32_t *rope_leaf, int32_t *prim_id,
                    void *stream) {
   if (!e) {

@@ -57,6 +57,9 @@ class Engine {
   // the assignment runs: core points keep their label, others take the smallest among their core neighbours
   void dbscan(float eps, int min_pts, int32_t *d_labels, uint8_t *d_core, int32_t *d_counts, tknnDbscanInfo *info,
               hipStream_t s, const int32_t *core_label = nullptr);
+  // "eps auto-grown" (BASELINE config 5; spec: oracle/dbscan_oracle.c dbref_dbscan_auto)
+  void dbscan_auto(float eps0, int min_pts, double max_noise, int max_rounds, int32_t *d_labels, uint8_t *d_core,
+                   tknnDbscanAutoInfo *info, hipStream_t s);
   bool built() const { return bvh_.built(); }
   int device() const { return device_; }
   int64_t size() const { return bvh_.size(); }

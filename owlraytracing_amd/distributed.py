@@ -478,6 +478,23 @@ class ShardedTrueKNN:
         info = {"clusters": int(len(everyone)), "rounds": rounds, "halo_points": int(len(halo))}
         return {"labels": labels[:m].to(dev), "core": core[:m], "info": info}
 
+    def dbscan_auto(self, eps0, min_pts, max_noise=0.05, max_rounds=32):
+        """RT-DBSCAN with an auto-grown eps over the tiles (spec: oracle/dbscan_oracle.c, dbref_dbscan_auto): rounds of the
+        sharded DBSCAN above with eps doubling (fp32, hostCode.cpp:321) until at most floor(max_noise * n_total) points of
+        the WHOLE set are noise -- one 8-byte all-reduce per round; the final round's halo has radius 2 * eps_final."""
+        comm, dev = self.comm, self.device
+        bound = int(np.floor(float(max_noise) * self.n_total))
+        eps = np.float32(eps0)
+        for t in range(int(max_rounds)):
+            r = self.dbscan(float(eps), min_pts)
+            noise = torch.tensor([int((r["labels"] < 0).sum().item())], dtype=torch.int64, device=dev)
+            comm.all_reduce(noise, dist.ReduceOp.SUM)
+            r["info"].update({"rounds": t + 1, "eps": float(eps), "noise": int(noise.item())})
+            if int(noise.item()) <= bound:
+                return r
+            eps = np.float32(eps * np.float32(2))
+        raise _lib.TknnError(-4, "max_rounds doublings of eps did not bring the noise under the bound")
+
     def gather_rows(self):
         """(global_ids, idx, dist, intersections) of every rank concatenated on every rank (tests)."""
         comm, dev = self.comm, self.device

@@ -189,6 +189,20 @@ class TrueKNN:
             out["counts"] = counts
         return out
 
+    def dbscan_auto(self, eps0, min_pts, max_noise=0.05, max_rounds=32):
+        """RT-DBSCAN with an auto-grown eps (tknnDbscanAuto): eps doubles from ``eps0`` until at most
+        floor(max_noise * n) points are noise.  dict(labels, core, info(rounds, eps, noise, clusters, ...))."""
+        torch = self._torch
+        n = self.n
+        with torch.cuda.device(self.device):
+            labels = torch.empty((n,), dtype=torch.int32, device=self.device)
+            core = torch.empty((n,), dtype=torch.uint8, device=self.device)
+            info = _lib.DbscanAutoInfo()
+            _lib.check(self._lib.tknnDbscanAuto(self._h, ctypes.c_float(eps0), int(min_pts), ctypes.c_double(max_noise), int(max_rounds),
+                                                ctypes.c_void_p(labels.data_ptr()), ctypes.c_void_p(core.data_ptr()),
+                                                ctypes.byref(info), self._stream()))
+        return {"labels": labels, "core": core.bool(), "info": info.as_dict()}
+
     def dbscan_assign(self, eps, core_label):
         """Last step of DBSCAN with labels decided by the caller: ``core_label`` (n,) int32, >= 0 for
         core points.  Returns labels (n,) int32: core points keep theirs, the others take the smallest

@@ -104,7 +104,11 @@ def main():
     else:
         solver.load_points(torch.from_numpy(pts[lo:hi]), torch.arange(lo, hi, dtype=torch.int32))
     if os.environ.get("DBSCAN_EPS"):
-        r = solver.dbscan(float(os.environ["DBSCAN_EPS"]), int(os.environ.get("DBSCAN_MINPTS", "4")))
+        if os.environ.get("DBSCAN_MAX_NOISE"):  # the auto-grown eps: DBSCAN_EPS is eps0
+            r = solver.dbscan_auto(float(os.environ["DBSCAN_EPS"]), int(os.environ.get("DBSCAN_MINPTS", "4")),
+                                   max_noise=float(os.environ["DBSCAN_MAX_NOISE"]))
+        else:
+            r = solver.dbscan(float(os.environ["DBSCAN_EPS"]), int(os.environ.get("DBSCAN_MINPTS", "4")))
         rows = torch.cat([solver.ids.view(-1, 1).double().cpu(), r["labels"].view(-1, 1).double().cpu(),
                           r["core"].view(-1, 1).double().cpu()], dim=1).to(dev)
         got = torch.cat(solver.comm.exchange_rows([rows for _ in range(world)], 3, torch.float64, dev), dim=0).cpu().numpy()
@@ -113,7 +117,8 @@ def main():
                                                                     r["info"]["clusters"], r["info"]["rounds"]), flush=True)
         if rank == 0:
             np.savez(out, gids=got[:, 0].astype(np.int64), labels=got[:, 1].astype(np.int32), core=got[:, 2].astype(bool),
-                     clusters=r["info"]["clusters"])
+                     clusters=r["info"]["clusters"], eps=r["info"].get("eps", 0.0), eps_rounds=r["info"].get("rounds", 0),
+                     noise=r["info"].get("noise", -1))
         dist.barrier()
         dist.destroy_process_group()
         return

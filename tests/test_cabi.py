@@ -60,7 +60,7 @@ def test_ctypes_structs_have_the_header_layout(tmp_path):
     import ctypes
     import subprocess
     pairs = {"tknnSolveInfo": _lib.SolveInfo, "tknnSolveOptions": _lib.SolveOptions,
-             "tknnDbscanInfo": _lib.DbscanInfo, "tknnBuildInfo": _lib.BuildInfo}
+             "tknnDbscanInfo": _lib.DbscanInfo, "tknnDbscanAutoInfo": _lib.DbscanAutoInfo, "tknnBuildInfo": _lib.BuildInfo}
     lines = ["#include <stdio.h>", "#include <stddef.h>", '#include "owlknn.h"', "int main(void) {"]
     for cname, cls in pairs.items():
         lines.append('  printf("%s size %%zu\\n", sizeof(%s));' % (cname, cname))

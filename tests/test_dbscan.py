@@ -217,3 +217,51 @@ def test_config3_full_size():
     assert np.array_equal(core, full["core"])
     assert np.array_equal(lab, full["labels"])
     eng.close()
+
+
+def test_auto_grown_eps_spec():
+    """dbref_dbscan_auto: the rounds are plain DBSCAN runs at eps0 * 2^t (fp32 doubling), the first whose noise is under
+    the bound wins; noise never grows with eps; a generous eps0 takes one round."""
+    xyz = datasets.pad_to_3d(datasets.taxi_like2d(8000, components=12, seed=5))
+    eps0, min_pts = float(np.float32(0.0004)), 4
+    noises, eps = [], np.float32(eps0)
+    for _ in range(8):
+        noises.append(int((oracle.dbscan(xyz, float(eps), min_pts)["labels"] < 0).sum()))
+        eps = np.float32(eps * np.float32(2))
+    assert all(a >= b for a, b in zip(noises, noises[1:])), noises
+    for max_noise in (0.5, 0.1, 0.01):
+        bound = int(np.floor(max_noise * len(xyz)))
+        want = next(t for t, m in enumerate(noises) if m <= bound)
+        r = oracle.dbscan_auto(xyz, eps0, min_pts, max_noise)
+        assert r["rounds"] == want + 1 and r["noise"] == noises[want]
+        assert r["eps"] == float(np.float32(eps0) * np.float32(2.0 ** want))
+        plain = oracle.dbscan(xyz, r["eps"], min_pts)
+        assert np.array_equal(r["labels"], plain["labels"]) and np.array_equal(r["core"], plain["core"])
+    assert oracle.dbscan_auto(xyz, 0.05, min_pts, 0.01)["rounds"] == 1
+    with pytest.raises(oracle.OracleError):
+        oracle.dbscan_auto(xyz, 1e-7, min_pts, 0.0, max_rounds=3)
+
+
+@pytest.mark.gpu
+def test_hip_dbscan_auto_equals_the_spec():
+    from owlraytracing_amd import _lib
+    from owlraytracing_amd.trueknn import TrueKNN
+    eng = TrueKNN()
+    for name, xyz, eps0, min_pts, max_noise in (
+            ("taxi2d", datasets.pad_to_3d(datasets.taxi_like2d(300_000, components=64, seed=2)), 0.00005, 4, 0.05),
+            ("blobs3d", datasets.gaussian_mixture3d(200_000, components=32, sigma=0.02, seed=8), 0.0008, 6, 0.01),
+            ("one_round", datasets.uniform3d(50_000, seed=4), 0.2, 3, 0.0)):
+        eps0 = float(np.float32(eps0))
+        ref = oracle.dbscan_auto(xyz, eps0, min_pts, max_noise)
+        eng.build(xyz)
+        got = eng.dbscan_auto(eps0, min_pts, max_noise)
+        info = got["info"]
+        assert (info["rounds"], info["eps"], info["noise"], info["clusters"]) == (ref["rounds"], ref["eps"], ref["noise"], ref["clusters"]), name
+        assert np.array_equal(got["labels"].cpu().numpy(), ref["labels"]), name
+        assert np.array_equal(got["core"].cpu().numpy(), ref["core"]), name
+    with pytest.raises(_lib.TknnError):  # rounds run out
+        eng.dbscan_auto(1e-9, 3, 0.0, max_rounds=2)
+    for bad in ((0.0, 3, 0.1), (0.1, 0, 0.1), (0.1, 3, 1.5), (float("nan"), 3, 0.1)):
+        with pytest.raises(_lib.TknnError):
+            eng.dbscan_auto(*bad)
+    eng.close()

@@ -127,6 +127,30 @@ def test_sharded_dbscan_equals_the_single_process_spec(tmp_path, world, name, n,
     _check_dbscan(got, name, n, eps, min_pts)
 
 
+def test_sharded_dbscan_with_auto_grown_eps_equals_the_spec(tmp_path):
+    """BASELINE config 5's rule over tiles: eps doubles until the noise share of the WHOLE set is under the bound."""
+    from dist_worker import make_points
+    n, eps0, min_pts, max_noise = 6000, float(np.float32(0.001)), 5, 0.08
+    got = _run("checker", 3, n, 4, "planar", tmp_path, 29675, {"DBSCAN_EPS": repr(eps0), "DBSCAN_MINPTS": str(min_pts),
+                                                              "DBSCAN_MAX_NOISE": repr(max_noise)})
+    ref = oracle.dbscan_auto(make_points("planar", n), eps0, min_pts, max_noise)
+    assert ref["rounds"] > 1, "the start value must be too small for the test to mean anything"
+    assert int(got["eps_rounds"]) == ref["rounds"] and float(got["eps"]) == ref["eps"] and int(got["noise"]) == ref["noise"]
+    assert np.array_equal(got["labels"], ref["labels"]) and np.array_equal(got["core"], ref["core"])
+
+
+@pytest.mark.gpu
+def test_sharded_dbscan_auto_with_the_hip_engine(tmp_path):
+    from dist_worker import make_points
+    n, eps0, min_pts, max_noise = 200_000, float(np.float32(0.0015)), 5, 0.03
+    got = _run("hip", 3, n, 4, "clustered", tmp_path, 29676, {"DBSCAN_EPS": repr(eps0), "DBSCAN_MINPTS": str(min_pts),
+                                                               "DBSCAN_MAX_NOISE": repr(max_noise)})
+    ref = oracle.dbscan_auto(make_points("clustered", n), eps0, min_pts, max_noise)
+    assert ref["rounds"] > 1
+    assert int(got["eps_rounds"]) == ref["rounds"] and float(got["eps"]) == ref["eps"] and int(got["noise"]) == ref["noise"]
+    assert np.array_equal(got["labels"], ref["labels"]) and np.array_equal(got["core"], ref["core"])
+
+
 @pytest.mark.gpu
 def test_sharded_dbscan_with_the_hip_engine(tmp_path):
     n, eps, min_pts = 300_000, float(np.float32(0.012)), 5
