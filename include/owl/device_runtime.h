@@ -84,7 +84,8 @@ struct BlockState {
   uint32_t sbt_lo[OWL_RAYGEN_BLOCK], sbt_hi[OWL_RAYGEN_BLOCK];      // current program's data pointer
   uint32_t inst_id[OWL_RAYGEN_BLOCK], inst_index[OWL_RAYGEN_BLOCK];
   uint32_t hit_kind[OWL_RAYGEN_BLOCK], hit_attr[2][OWL_RAYGEN_BLOCK];
-  uint32_t flags[OWL_RAYGEN_BLOCK];  // bit 0: terminate requested
+  uint32_t flags[OWL_RAYGEN_BLOCK];  // bit 0: terminate requested, bit 1: a hit is recorded, bit 2: the any-hit program ignored the candidate
+  uint32_t anyhit_lo[OWL_RAYGEN_BLOCK], anyhit_hi[OWL_RAYGEN_BLOCK];  // __anyhit__ program of the geometry whose intersection program runs (0: none)
 };
 static __shared__ BlockState owl_block_state;
 
@@ -158,19 +159,38 @@ __device__ __forceinline__ unsigned int optixGetHitKind() { return owl::device::
 __device__ __forceinline__ unsigned int optixGetAttribute_0() { return owl::device::state().hit_attr[0][owl::device::tid()]; }
 __device__ __forceinline__ unsigned int optixGetAttribute_1() { return owl::device::state().hit_attr[1][owl::device::tid()]; }
 __device__ __forceinline__ void optixTerminateRay() { owl::device::state().flags[owl::device::tid()] |= 1u; }
-__device__ __forceinline__ void optixIgnoreIntersection() {}
+// any-hit programs: reject the candidate the intersection program has just reported (the ray keeps its tmax)
+__device__ __forceinline__ void optixIgnoreIntersection() { owl::device::state().flags[owl::device::tid()] |= 4u; }
 
-// An intersection program reports a hit at parameter t: accepted if inside (tmin, tmax) of the
-// current ray, in which case the ray is shortened to t (closest-hit semantics).
+// An intersection program reports a hit at parameter t: a candidate if inside (tmin, tmax) of the current
+// ray.  The geometry's any-hit program, if it has one for this ray type, then sees the candidate (t as the
+// ray's tmax, hit kind and attributes) and may reject it with optixIgnoreIntersection or accept it and end
+// the traversal with optixTerminateRay; an accepted candidate shortens the ray to t (closest-hit
+// semantics).  Returns whether the hit was accepted, like OptiX.
 __device__ __forceinline__ bool optixReportIntersection(float t, unsigned int kind, unsigned int a0 = 0,
                                                         unsigned int a1 = 0) {
   const uint32_t i = owl::device::tid();
   owl::device::BlockState &s = owl::device::state();
   if (!(t > s.tmin[i]) || !(t < s.tmax[i])) return false;
+  const float old_tmax = s.tmax[i];
+  const uint32_t old_kind = s.hit_kind[i], old_a0 = s.hit_attr[0][i], old_a1 = s.hit_attr[1][i];
   s.tmax[i] = t;
   s.hit_kind[i] = kind;
   s.hit_attr[0][i] = a0;
   s.hit_attr[1][i] = a1;
+  const uint64_t any_hit = ((uint64_t)s.anyhit_hi[i] << 32) | s.anyhit_lo[i];
+  if (any_hit) {
+    s.flags[i] &= ~4u;
+    ((owl::device::ProgramFn)any_hit)();
+    if (s.flags[i] & 4u) {  // ignored: as if nothing had been reported
+      s.flags[i] &= ~4u;
+      s.tmax[i] = old_tmax;
+      s.hit_kind[i] = old_kind;
+      s.hit_attr[0][i] = old_a0;
+      s.hit_attr[1][i] = old_a1;
+      return false;
+    }
+  }
   s.flags[i] |= 2u;  // a hit is recorded
   return true;
 }
@@ -228,6 +248,9 @@ __device__ __forceinline__ void trace_user_group(const UserGroupAccel *accel, un
         if (fn) {
           s.prim[i] = prim - rec.prim_begin;
           set_sbt(rec.data);
+          const uint64_t ah = rec.any_hit[ray_type < OWL_MAX_RAY_TYPES ? ray_type : 0];
+          s.anyhit_lo[i] = (uint32_t)ah;
+          s.anyhit_hi[i] = (uint32_t)(ah >> 32);
           const uint32_t had = s.flags[i] & 2u;
           s.flags[i] &= ~2u;
           ((ProgramFn)fn)();

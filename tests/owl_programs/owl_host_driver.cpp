@@ -10,6 +10,9 @@
 //   owl_host_driver count  <module.hsaco> <points.f32> <n> <radius> <out.bin>
 //       tests/owl_programs/radius_programs.cu: per-point neighbour count / nearest / IS calls, then
 //       a first-hit pass (closest-hit + miss programs); two geometries in one group.
+//   owl_host_driver api    <api_programs.hsaco> <out.bin>
+//       tests/owl_programs/api_programs.cu: OWL_BUFFER / OWL_BUFFER_SIZE / OWL_DEVICE variables, host-pinned output,
+//       owlBufferUpload / Resize / Destroy, any-hit, instance transforms and ids, two OWLParams launched asynchronously.
 //   owl_host_driver errors <module.hsaco>
 //       the error conventions of SURVEY.md section 8(b); prints one PASS/FAIL line per check.
 #include <owl/owl.h>
@@ -250,6 +253,139 @@ static int run_count(int argc, char **argv) {
   return 0;
 }
 
+
+// tests/owl_programs/api_programs.cu layouts
+struct CubesGeomRec {
+  Point3 *centers;
+  float half;
+  int reject_odd;
+};
+struct DeviceBufferRec {
+  int type;
+  int pad;
+  unsigned long long count;
+  void *data;
+};
+struct ApiParamsRec {
+  DeviceBufferRec out;
+  unsigned long long out_size;
+  float *hit_t;
+  Point3 *origins;
+  int tag;
+};
+struct ApiRayGenRec {
+  OptixTraversableHandle world;
+  int device;
+  int n;
+};
+
+// Scene: four cubes of half-width 0.25 on the line y = z = 0 at x = 1, 2, 3, 4 (primitives 0..3), instanced twice:
+// instance 0 (id 70) as it is, instance 1 (id 71) moved by (+0.5, +10, 0).  Rays along +x.
+//   pass A  reject_odd = 0: a ray from x = 0 on the line hits prim 0 of instance 0 at t = 0.75; one from y = 10 hits
+//           prim 0 of instance 1 at t = 1.25 (object-space origin is shifted back by the instance transform).
+//   pass B  reject_odd = 1 (any-hit ignores odd primitives): a ray starting at x = 1.5 skips prim 1 and ends on prim 2.
+// Output file: for each pass and query int4 {prim, instance id, device, tag} + float t.
+static int run_api(int argc, char **argv) {
+  if (argc < 4) return 2;
+  std::vector<char> code = read_file(argv[2]);
+  int32_t two_ids[2] = {0, 0};
+  OWLContext ctx = owlContextCreate(two_ids, 2);  // two devices asked for: the context spans one
+  const int device_count = owlGetDeviceCount(ctx);
+  OWLModule mod = owlModuleCreate(ctx, code.data());
+  OWLVarDecl geomVars[] = {{"centers", OWL_BUFPTR, OWL_OFFSETOF(CubesGeomRec, centers)},
+                           {"half", OWL_FLOAT, OWL_OFFSETOF(CubesGeomRec, half)},
+                           {"reject_odd", OWL_INT, OWL_OFFSETOF(CubesGeomRec, reject_odd)},
+                           {nullptr, OWL_INVALID_TYPE, 0}};
+  OWLGeomType type = owlGeomTypeCreate(ctx, OWL_GEOMETRY_USER, sizeof(CubesGeomRec), geomVars, -1);
+  owlGeomTypeSetIntersectProg(type, 0, mod, "Cubes");
+  owlGeomTypeSetClosestHit(type, 0, mod, "Cubes");
+  owlGeomTypeSetAnyHit(type, 0, mod, "Cubes");
+  owlGeomTypeSetBoundsProg(type, mod, "Cubes");
+  OWLVarDecl missVars[] = {{nullptr, OWL_INVALID_TYPE, 0}};
+  owlMissProgCreate(ctx, mod, "none", 0, missVars, -1);
+  owlBuildPrograms(ctx);
+  // centers: created too small and with wrong contents, then resized and uploaded in two pieces
+  Point3 wrong[2] = {{9, 9, 9}, {9, 9, 9}};
+  OWLBuffer centers = owlDeviceBufferCreate(ctx, OWL_USER_TYPE(Point3), 2, wrong);
+  owlBufferResize(centers, 4);
+  Point3 cubes[4] = {{1, 0, 0}, {2, 0, 0}, {3, 0, 0}, {4, 0, 0}};
+  owlBufferUpload(centers, cubes, 0, 2 * sizeof(Point3));
+  owlBufferUpload(centers, cubes + 2, 2 * sizeof(Point3), 2 * sizeof(Point3));
+  OWLBuffer scratch = owlDeviceBufferCreate(ctx, OWL_INT, 1000, nullptr);
+  owlBufferDestroy(scratch);  // must not disturb anything else
+  OWLGeom geom = owlGeomCreate(ctx, type);
+  owlGeomSetPrimCount(geom, 4);
+  owlGeomSetBuffer(geom, "centers", centers);
+  owlGeomSet1f(geom, "half", 0.25f);
+  owlGeomSet1i(geom, "reject_odd", 0);
+  OWLGroup blas = owlUserGeomGroupCreate(ctx, 1, &geom);
+  owlGroupBuildAccel(blas);
+  OWLGroup both[2] = {blas, blas};
+  uint32_t ids[2] = {70, 71};
+  OWLGroup world = owlInstanceGroupCreate(ctx, 2, both, ids, nullptr, OWL_MATRIX_FORMAT_OWL);
+  // OWL format: column major 4x3 = {vx, vy, vz, translation}
+  const float moved[12] = {1, 0, 0, 0, 1, 0, 0, 0, 1, 0.5f, 10.f, 0.f};
+  owlInstanceGroupSetTransform(world, 1, moved, OWL_MATRIX_FORMAT_OWL);
+  owlGroupBuildAccel(world);
+  const int n = 4;
+  Point3 origins[n] = {{0, 0, 0}, {0, 10, 0}, {1.5f, 0.1f, 0}, {0, 5, 0}};
+  OWLBuffer org = owlDeviceBufferCreate(ctx, OWL_USER_TYPE(Point3), n, origins);
+  OWLBuffer outA = owlDeviceBufferCreate(ctx, OWL_INT4, n, nullptr), outB = owlDeviceBufferCreate(ctx, OWL_INT4, n, nullptr);
+  OWLBuffer tA = owlHostPinnedBufferCreate(ctx, OWL_FLOAT, n), tB = owlHostPinnedBufferCreate(ctx, OWL_FLOAT, n);
+  OWLVarDecl lpVars[] = {{"out", OWL_BUFFER, OWL_OFFSETOF(ApiParamsRec, out)},
+                         {"out_size", OWL_BUFFER_SIZE, OWL_OFFSETOF(ApiParamsRec, out_size)},
+                         {"hit_t", OWL_BUFPTR, OWL_OFFSETOF(ApiParamsRec, hit_t)},
+                         {"origins", OWL_BUFPTR, OWL_OFFSETOF(ApiParamsRec, origins)},
+                         {"tag", OWL_INT, OWL_OFFSETOF(ApiParamsRec, tag)},
+                         {nullptr, OWL_INVALID_TYPE, 0}};
+  OWLParams lpA = owlParamsCreate(ctx, sizeof(ApiParamsRec), lpVars, -1), lpB = owlParamsCreate(ctx, sizeof(ApiParamsRec), lpVars, -1);
+  owlParamsSetBuffer(lpA, "out", outA);
+  owlParamsSetBuffer(lpA, "out_size", outA);
+  owlParamsSetBuffer(lpA, "hit_t", tA);
+  owlParamsSetBuffer(lpA, "origins", org);
+  owlParamsSet1i(lpA, "tag", 1001);
+  owlParamsSetBuffer(lpB, "out", outB);
+  owlParamsSetBuffer(lpB, "out_size", outB);
+  owlParamsSetBuffer(lpB, "hit_t", tB);
+  owlParamsSetBuffer(lpB, "origins", org);
+  owlParamsSet1i(lpB, "tag", 2002);
+  OWLVarDecl rgVars[] = {{"world", OWL_GROUP, OWL_OFFSETOF(ApiRayGenRec, world)},
+                         {"device", OWL_DEVICE, OWL_OFFSETOF(ApiRayGenRec, device)},
+                         {"n", OWL_INT, OWL_OFFSETOF(ApiRayGenRec, n)},
+                         {nullptr, OWL_INVALID_TYPE, 0}};
+  OWLRayGen rg = owlRayGenCreate(ctx, mod, "shoot", sizeof(ApiRayGenRec), rgVars, -1);
+  owlRayGenSetGroup(rg, "world", world);
+  owlRayGenSet1i(rg, "n", n);
+  owlBuildPrograms(ctx);
+  owlBuildPipeline(ctx);
+  owlBuildSBT(ctx);
+  std::vector<char> out;
+  auto append = [&](OWLBuffer ob, OWLBuffer tb) {
+    std::vector<int> prim(4 * n);
+    CUDA_CHECK(cudaMemcpy(prim.data(), owlBufferGetPointer(ob, 0), prim.size() * 4, cudaMemcpyDeviceToHost));
+    const float *t = (const float *)owlBufferGetPointer(tb, 0);  // host-pinned: read where it lies
+    out.insert(out.end(), (const char *)prim.data(), (const char *)(prim.data() + prim.size()));
+    out.insert(out.end(), (const char *)t, (const char *)(t + n));
+  };
+  // pass A: two OWLParams, launched asynchronously back to back on the same raygen, then both waited for --
+  // each launch must see its own parameters (the code object has ONE `optixLaunchParams`)
+  owlAsyncLaunch2D(rg, n, 1, lpA);
+  owlAsyncLaunch2D(rg, n, 1, lpB);
+  owlLaunchSync(lpA);
+  owlLaunchSync(lpB);
+  append(outA, tA);
+  append(outB, tB);
+  // pass B: the any-hit program rejects odd primitives (the geometry's variable changes: SBT rebuilt)
+  owlGeomSet1i(geom, "reject_odd", 1);
+  owlBuildSBT(ctx);
+  owlLaunch2D(rg, n, 1, lpA);
+  append(outA, tA);
+  write_file(argv[3], out.data(), out.size());
+  std::printf("device_count=%d\n", device_count);
+  owlContextDestroy(ctx);
+  return 0;
+}
+
 static int checks = 0, failures = 0;
 static void expect_throw(const char *what, const std::function<void()> &f, const char *needle = nullptr) {
   checks++;
@@ -324,6 +460,7 @@ int main(int argc, char **argv) {
     if (!std::strcmp(argv[1], "knn")) return run_knn(argc, argv);
     if (!std::strcmp(argv[1], "count")) return run_count(argc, argv);
     if (!std::strcmp(argv[1], "errors")) return run_errors(argc, argv);
+    if (!std::strcmp(argv[1], "api")) return run_api(argc, argv);
   } catch (const std::exception &e) {
     std::fprintf(stderr, "uncaught: %s\n", e.what());
     return 3;

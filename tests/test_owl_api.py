@@ -179,3 +179,98 @@ def test_unchanged_reference_sample_runs(tmp_path):
     assert r.stdout.count("Round: ") == 2 * ref["rounds"]  # header line + timing line per round
     assert "True KNN time" in r.stdout and "Build time" in r.stdout
     assert float(timefile.read_text().split()[0]) > 0
+
+
+API_HSACO = os.path.join(BUILD, "api_programs.hsaco")
+
+
+@pytest.mark.gpu
+def test_rest_of_the_owl_surface(tmp_path):
+    """SURVEY 8f-1 on the GPU (tests/owl_programs/api_programs.cu + `owl_host_driver api`): OWL_BUFFER / OWL_BUFFER_SIZE /
+    OWL_DEVICE variables, a host-pinned output buffer read in place, owlBufferResize + two partial owlBufferUpload,
+    owlBufferDestroy, instance transforms and ids, any-hit programs (optixIgnoreIntersection), and two OWLParams
+    launched asynchronously on one raygen -- each launch sees its own parameters although the code object has a
+    single `optixLaunchParams` (reference: a device buffer per LaunchParams, owl/LaunchParams.cpp:38-49)."""
+    if not os.path.exists(API_HSACO) or not os.path.exists(DRIVER):
+        subprocess.check_call(["bash", os.path.join(ROOT, "tests", "owl_programs", "build.sh")])
+    out = tmp_path / "api.bin"
+    r = subprocess.run([DRIVER, "api", API_HSACO, str(out)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    # a context asked to span two devices spans one (owlGetDeviceCount says so, OWL_DEVICE variables read 0)
+    assert "device_count=1" in r.stdout
+    raw = out.read_bytes()
+    n = 4
+    rec = np.dtype([("hit", np.int32, (n, 4)), ("t", np.float32, (n,))])
+    a, b, c = np.frombuffer(raw, dtype=rec)
+    # pass A, OWLParams A and B launched back to back: same hits, each with ITS tag
+    for got, tag in ((a, 1001), (b, 2002)):
+        assert got["hit"][:, 3].tolist() == [tag] * n
+        assert got["hit"][:, 2].tolist() == [0] * n                      # OWL_DEVICE
+        assert got["hit"][0].tolist()[:2] == [0, 70] and got["t"][0] == np.float32(0.75)   # instance 0, cube 0
+        assert got["hit"][1].tolist()[:2] == [0, 71] and got["t"][1] == np.float32(1.25)   # moved instance: (1 + 0.5 - 0.25) - 0
+        assert got["hit"][2].tolist()[:2] == [1, 70] and got["t"][2] == np.float32(0.25)   # starts inside cube 0's shadow: next is cube 1 at x = 1.75
+        assert got["hit"][3].tolist()[:2] == [-1, -1] and got["t"][3] == np.float32(-1.0)  # between the instances: miss program
+    # pass B: the any-hit program ignores odd primitives
+    assert c["hit"][0].tolist()[:2] == [0, 70]
+    assert c["hit"][2].tolist()[:2] == [2, 70] and c["t"][2] == np.float32(1.25)           # cube 1 ignored, cube 2 at x = 2.75
+    assert c["hit"][1].tolist()[:2] == [0, 71]
+    assert c["hit"][3].tolist()[:2] == [-1, -1]
+
+
+@pytest.mark.gpu
+def test_command_line_tool_with_a_sampled_start_radius(tmp_path):
+    """tools/trueknn_cli.py (the reference sample's argv, hostCode.cpp:66-73) with `auto`: the start radius comes from
+    owlraytracing_amd.radius.sample_start_radius (counterpart of samples/s01-trueknn/Util/random_sample.py), the rows
+    equal the CPU checker's for that radius, the reference's report lines are printed and the total is appended."""
+    import sys
+
+    import oracle
+    from owlraytracing_amd import datasets
+    from owlraytracing_amd.radius import sample_start_radius
+    n, k = 40_000, 7
+    pts = datasets.gaussian_mixture3d(n, components=9, sigma=0.04, seed=21)
+    csv = tmp_path / "pts.csv"
+    datasets.write_csv_points(str(csv), pts)
+    back = datasets.pad_to_3d(datasets.read_csv_points(str(csv), n, 3))
+    timefile, rows = tmp_path / "time.txt", tmp_path / "rows.npz"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "trueknn_cli.py"), str(csv), str(n), "3", "auto", str(k),
+                        str(timefile), "--out", str(rows)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    for needle in ("num spheres: %d" % n, "Build time:", "True KNN time:", "Total time:"):
+        assert needle in r.stdout
+    assert float(timefile.read_text().split()[0]) > 0
+    r0 = sample_start_radius(back)
+    ref = oracle.trueknn(back, k, r0)
+    z = np.load(rows)
+    assert np.array_equal(z["idx"], ref["idx"]) and np.array_equal(z["dist"], ref["dist"])
+    assert np.array_equal(z["intersections"], ref["intersections"])
+    assert "Rounds: %d " % ref["rounds"] in r.stdout
+
+
+def test_reference_sample_configures_and_builds_through_the_cmake_module(tmp_path):
+    """cmake/owl_mi355x.cmake stands in for the reference's owl/cmake/configure_owl.cmake + configure_optix.cmake: the
+    UNCHANGED samples/s01-trueknn/CMakeLists.txt (cuda_compile_and_embed at :19-21, OWL_LIBRARIES at :27-30) configures
+    and builds against it -- hipcc cross-compiles deviceCode.cu for gfx950, no GPU needed.  Needs the reference tree
+    (present in the build container only)."""
+    ref_sample = "/root/reference/samples/s01-trueknn"
+    if not os.path.exists(os.path.join(ref_sample, "CMakeLists.txt")):
+        pytest.skip("no reference tree here")
+    import shutil
+    if not shutil.which("cmake") or not os.path.exists("/opt/rocm/bin/hipcc"):
+        pytest.skip("cmake or hipcc missing")
+    from owlraytracing_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        pytest.skip("library not built")
+    (tmp_path / "CMakeLists.txt").write_text(
+        "cmake_minimum_required(VERSION 3.16)\nproject(owl_on_mi355x C CXX)\nenable_testing()\n"
+        "include(%s)\nadd_subdirectory(%s ${CMAKE_BINARY_DIR}/s01-trueknn)\n" % (os.path.join(ROOT, "cmake", "owl_mi355x.cmake"), ref_sample))
+    build = tmp_path / "build"
+    r = subprocess.run(["cmake", "-S", str(tmp_path), "-B", str(build), "-DCMAKE_BUILD_TYPE=Release"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    r = subprocess.run(["cmake", "--build", str(build), "-j", "4"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    exe = build / "s01-trueknn" / "sample01-trueknn"
+    assert exe.exists()
+    # the embedded device code is a gfx950 code object under the symbol the sample declares (hostCode.cpp:52)
+    syms = subprocess.run(["nm", "-C", str(exe)], capture_output=True, text=True).stdout
+    assert " ptxCode" in syms
