@@ -273,9 +273,19 @@ struct Buffer : Object {
   OWLDataType type;
   size_t count;
   void *ptr = nullptr;
+  // Managed buffers in "mirror" form (the default, see managed_policy): `ptr` is DEVICE memory -- what BUFPTR
+  // variables hand to device code -- and `mirror` a pinned host copy -- what owlBufferGetPointer hands to host code.
+  // Both sides see one coherent buffer at the API's synchronisation points: the mirror is refreshed by one bulk
+  // copy when the host asks for the pointer after a launch, and written back before the next launch.
+  void *mirror = nullptr;
+  bool mirrored = false;      // this buffer uses the mirror form
+  bool device_newer = false;  // a launch ran since the mirror was last refreshed
+  bool host_may_have_written = false;  // the host has held the mirror's pointer since the last write-back
   size_t elem() const { return size_of_type(type); }
   size_t bytes() const { return elem() * count; }
   void release() {
+    if (mirror) (void)hipHostFree(mirror);
+    mirror = nullptr;
     if (!ptr) return;
     if (bkind == BufferKind::HostPinned)
       (void)hipHostFree(ptr);
@@ -283,6 +293,8 @@ struct Buffer : Object {
       (void)hipFree(ptr);
     ptr = nullptr;
   }
+  const void *host_pointer();  // owlBufferGetPointer
+  void write_back(hipStream_t s);  // before a launch
   void allocate(const void *init);
   void resize(size_t n) {
     release();
@@ -445,17 +457,31 @@ void check_decls(const std::vector<VarDecl> &decls, size_t bytes) {
       fail("variable '" + d.name + "' does not fit the declared struct size");
 }
 
+int managed_policy();
+
 void Buffer::allocate(const void *init) {
   const size_t n = bytes();
   if (bkind == BufferKind::Device) {
     OWL_HIP(hipMalloc(&ptr, n ? n : 16));
     if (init && n) OWL_HIP(hipMemcpy(ptr, init, n, hipMemcpyHostToDevice));
+  } else if (bkind == BufferKind::Managed && managed_policy() == 4) {
+    // mirror form: device memory + pinned host copy (one address per side; see struct Buffer)
+    mirrored = true;
+    OWL_HIP(hipMalloc(&ptr, n ? n : 16));
+    OWL_HIP(hipHostMalloc(&mirror, n ? n : 16, hipHostMallocDefault));
+    if (init && n) {
+      std::memcpy(mirror, init, n);
+      OWL_HIP(hipMemcpy(ptr, mirror, n, hipMemcpyHostToDevice));
+    }
+    device_newer = false;
+    host_may_have_written = false;
   } else if (bkind == BufferKind::Managed) {
     // one address valid on host and device (owlBufferGetPointer is read on the host by
     // samples/s01-trueknn/hostCode.cpp:294-313)
+    mirrored = false;
     OWL_HIP(hipMallocManaged(&ptr, n ? n : 16, hipMemAttachGlobal));
     if (init && n) std::memcpy(ptr, init, n);
-    (void)hipMemAdvise(ptr, n ? n : 16, hipMemAdviseSetPreferredLocation, ctx->device);
+    if (managed_policy() != 2 && managed_policy() != 3) (void)hipMemAdvise(ptr, n ? n : 16, hipMemAdviseSetPreferredLocation, ctx->device);
     if (hipMemPrefetchAsync(ptr, n ? n : 16, ctx->device, ctx->stream) != hipSuccess) (void)hipGetLastError();
     OWL_HIP(hipStreamSynchronize(ctx->stream));
   } else {
@@ -696,6 +722,40 @@ void build_sbt(Context &c, int flags) {
   OWL_HIP(hipStreamSynchronize(s));
 }
 
+// How "managed" buffers (owlManagedMemoryBufferCreate) are kept coherent between launches and the host code that reads
+// them -- samples/s01-trueknn/hostCode.cpp:294-330 scans its n*k*24-byte frameBuffer after every launch.
+//   4 (default) mirror form: device memory for device code, a pinned host copy for owlBufferGetPointer, one bulk copy
+//     each way at the API's synchronisation points (struct Buffer).  The sample at 1 M points, k = 10: three rounds in
+//     about a quarter of the time of policy 0 (profiles/).
+//   0: hipMallocManaged, prefetched to the GPU before a launch, pulled back by the host's page faults (round 1: the
+//      migration path moves 240 MB in about 70 ms each way on this system).  1: also prefetched to the host after a
+//      synchronous launch (slower still).  2 / 3: as 1 / 0 without the preferred-location advice.
+// OWL_MANAGED_POLICY selects another one (measurements, or a host program that relies on ONE address for both sides).
+int managed_policy() {
+  static const int p = [] {
+    const char *e = getenv("OWL_MANAGED_POLICY");
+    return e ? atoi(e) : 4;
+  }();
+  return p;
+}
+
+const void *Buffer::host_pointer() {
+  if (!mirrored) return ptr;
+  if (device_newer && ptr) {
+    OWL_HIP(hipDeviceSynchronize());  // launches of every OWLParams stream that may still write the buffer
+    OWL_HIP(hipMemcpy(mirror, ptr, bytes() ? bytes() : 16, hipMemcpyDeviceToHost));
+    device_newer = false;
+  }
+  host_may_have_written = true;  // the caller holds a writable pointer from now on
+  return mirror;
+}
+
+void Buffer::write_back(hipStream_t s) {
+  if (!mirrored || !host_may_have_written || !ptr) return;
+  OWL_HIP(hipMemcpyAsync(ptr, mirror, bytes() ? bytes() : 16, hipMemcpyHostToDevice, s));
+  host_may_have_written = false;
+}
+
 void launch(RayGen &rg, int dx, int dy, Params *lp, bool sync) {
   Context &c = *rg.ctx;
   if (!rg.kernel) fail("raygen program not built: call owlBuildPrograms / owlBuildPipeline / owlBuildSBT before launching");
@@ -715,8 +775,14 @@ void launch(RayGen &rg, int dx, int dy, Params *lp, bool sync) {
   // managed buffers may have been paged to the host by the application between launches
   for (auto &wb : c.buffers)
     if (auto b = wb.lock())
-      if (b->bkind == BufferKind::Managed && b->ptr)
-        if (hipMemPrefetchAsync(b->ptr, b->bytes() ? b->bytes() : 16, c.device, s) != hipSuccess) (void)hipGetLastError();
+      if (b->bkind == BufferKind::Managed && b->ptr) {
+        if (b->mirrored) {
+          b->write_back(s);       // what the host may have written through owlBufferGetPointer's pointer
+          b->device_newer = true;  // ... and the launch may write the device side
+        } else if (hipMemPrefetchAsync(b->ptr, b->bytes() ? b->bytes() : 16, c.device, s) != hipSuccess) {
+          (void)hipGetLastError();
+        }
+      }
   rec::LaunchDesc desc;
   desc.dims[0] = (uint32_t)dx;
   desc.dims[1] = (uint32_t)dy;
@@ -732,6 +798,14 @@ void launch(RayGen &rg, int dx, int dy, Params *lp, bool sync) {
     OWL_HIP(hipEventRecord(m.params_free, s));
     m.params_stream = s;
     m.params_in_use = true;
+  }
+  if (sync && (managed_policy() == 1 || managed_policy() == 2)) {
+    // owlLaunch2D returns to host code that is about to read its managed buffers: one bulk transfer instead of a
+    // page fault per 4 KB touched
+    for (auto &wb : c.buffers)
+      if (auto b = wb.lock())
+        if (b->bkind == BufferKind::Managed && b->ptr && !b->mirrored)
+          if (hipMemPrefetchAsync(b->ptr, b->bytes() ? b->bytes() : 16, hipCpuDeviceId, s) != hipSuccess) (void)hipGetLastError();
   }
   if (sync) OWL_HIP(hipStreamSynchronize(s));
 }
@@ -1028,7 +1102,7 @@ OWL_API OWLBuffer owlHostPinnedBufferCreate(OWLContext c, OWLDataType t, size_t 
 OWL_API OWLBuffer owlGraphicsBufferCreate(OWLContext, OWLDataType, size_t, cudaGraphicsResource_t) { unsupported("graphics-interop buffers"); }
 OWL_API void owlGraphicsBufferMap(OWLBuffer) { unsupported("graphics-interop buffers"); }
 OWL_API void owlGraphicsBufferUnmap(OWLBuffer) { unsupported("graphics-interop buffers"); }
-OWL_API const void *owlBufferGetPointer(OWLBuffer buffer, int) { return get<Buffer>(buffer, Kind::Buffer)->ptr; }
+OWL_API const void *owlBufferGetPointer(OWLBuffer buffer, int) { return get<Buffer>(buffer, Kind::Buffer)->host_pointer(); }
 OWL_API void owlBufferResize(OWLBuffer buffer, size_t n) { get<Buffer>(buffer, Kind::Buffer)->resize(n); }
 OWL_API void owlBufferDestroy(OWLBuffer buffer) {
   auto b = get<Buffer>(buffer, Kind::Buffer);
@@ -1041,10 +1115,13 @@ OWL_API void owlBufferUpload(OWLBuffer buffer, const void *host, size_t offset, 
   if (!host) fail("owlBufferUpload: NULL source");
   if (numBytes == (size_t)-1) numBytes = b->bytes() - offset;
   if (offset + numBytes > b->bytes()) fail("owlBufferUpload: range exceeds the buffer");
-  if (b->bkind == BufferKind::Device)
+  if (b->bkind == BufferKind::Device) {
     OWL_HIP(hipMemcpy((char *)b->ptr + offset, host, numBytes, hipMemcpyHostToDevice));
-  else
+  } else if (b->mirrored) {
+    std::memcpy((char *)b->host_pointer() + offset, host, numBytes);  // (refreshes the mirror first; written back before the next launch)
+  } else {
     std::memcpy((char *)b->ptr + offset, host, numBytes);
+  }
 }
 
 OWL_API OWLTexture owlTexture2DCreate(OWLContext, OWLTexelFormat, uint32_t, uint32_t, const void *, OWLTextureFilterMode,
