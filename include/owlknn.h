@@ -152,6 +152,11 @@ typedef struct {
   int64_t *d_intersections;
   tknnNeigh *d_fb;
   int32_t *d_levels;
+  const float *d_start_radii; /* NULL, or n floats: row q starts with d_start_radii[q] instead of start_radius and doubles from
+                                 there -- a per-query radius schedule (opt-in: the reference has ONE
+                                 radius, samples/s01-trueknn/hostCode.cpp:185,325).  Row q is what the reference's loop gives
+                                 for q when started at that radius; every value must be finite and > 0.  Team kernels only
+                                 (k <= 64), no halo tree.  info->final_radius then refers to start_radius. */
 } tknnSolveOptions;
 TKNN_API int tknnBuildIds(tknnEngine e, const float *d_xyz, const int32_t *d_ids, int64_t n,
                           tknnBuildInfo *info, void *stream);

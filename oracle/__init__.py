@@ -20,4 +20,5 @@ from .loader import (  # noqa: F401
     distance,
     num_threads,
     trueknn,
+    trueknn_per_query,
 )

@@ -131,6 +131,28 @@ def trueknn(xyz, k, start_radius, order=ORDER_ASCENDING, seed=0, query_ids=None,
     }
 
 
+def trueknn_per_query(xyz, k, start_radii, max_rounds=64):
+    """The opt-in per-query radius schedule (tknnSolveOptions.d_start_radii): row q is what the
+    reference's loop (hostCode.cpp:285-340) produces for query q when it starts at start_radii[q] -- a row's result
+    never depends on other rows, so the queries of each distinct start radius are simply run as one reference solve of
+    their own.  Returns dict(idx, dist, intersections, rounds) with rounds = the largest number any query needed."""
+    xyz = _points(xyz)
+    n = len(xyz)
+    radii = np.ascontiguousarray(start_radii, dtype=np.float32)
+    if radii.shape != (n,):
+        raise ValueError("one start radius per point")
+    idx = np.empty((n, k), np.int32)
+    dist = np.empty((n, k), np.float32)
+    isect = np.empty(n, np.int64)
+    rounds = 0
+    for r in np.unique(radii):
+        q = np.flatnonzero(radii == r).astype(np.int32)
+        part = trueknn(xyz, k, float(r), query_ids=q, max_rounds=max_rounds)
+        idx[q], dist[q], isect[q] = part["idx"][q], part["dist"][q], part["intersections"][q]
+        rounds = max(rounds, part["rounds"])
+    return {"idx": idx, "dist": dist, "intersections": isect, "rounds": rounds}
+
+
 def bruteforce_knn(xyz, k, query_ids=None):
     lib = _load()
     xyz = _points(xyz)

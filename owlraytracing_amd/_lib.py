@@ -57,6 +57,7 @@ class SolveOptions(ctypes.Structure):
         ("d_intersections", ctypes.c_void_p),
         ("d_fb", ctypes.c_void_p),
         ("d_levels", ctypes.c_void_p),
+        ("d_start_radii", ctypes.c_void_p),
     ]
 
 

@@ -531,6 +531,10 @@ void Engine::solve(const SolveArgs &sa, int kernel, tknnSolveInfo *info, hipStre
   // Rows whose order depends on how bit-identical fp32 distances are ordered: every kernel lists by
   // (dist, index) and flags them in tie_; fix_ties redoes them in the reference's order, by the round in
   // which each neighbour was first a candidate (deviceCode.cu:77-85 -- lists persist over rounds).
+  if (sa.d_start_radii && (kernel != TKNN_KERNEL_TEAM || bvh_.size() >= (1ll << 28)))
+    throw ArgError{TKNN_E_UNSUPPORTED, "tknnSolveEx: per-query start radii are served by the team kernels only (k <= 64)"};
+  if (sa.d_start_radii && halo_count() > 0)
+    throw ArgError{TKNN_E_UNSUPPORTED, "tknnSolveEx: per-query start radii and a halo tree do not combine (the halo is exchanged for ONE radius)"};
   if (sa.phase != 0) {
     if (kernel != TKNN_KERNEL_TEAM || bvh_.size() >= (1ll << 28))
       throw ArgError{TKNN_E_UNSUPPORTED, "tknnSolveEx: phases (interior / boundary queries) are served by the team kernels only"};
@@ -734,6 +738,7 @@ int tknnSolveEx(tknnEngine e, const tknnSolveOptions *options, tknnSolveInfo *in
     sa.d_levels = options->d_levels;
     sa.allow_unfinished = options->allow_unfinished != 0;
     sa.phase = options->phase;
+    sa.d_start_radii = options->d_start_radii;
     if (sa.phase < 0 || sa.phase > 2) throw owlmi::ArgError{TKNN_E_ARG, "tknnSolveEx: phase must be 0 (all), 1 (interior) or 2 (boundary)"};
     if (info) std::memset(info, 0, sizeof(*info));
     e->impl.solve(sa, kernel, info, (hipStream_t)stream);

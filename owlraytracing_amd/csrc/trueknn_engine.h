@@ -27,6 +27,7 @@ struct SolveArgs {
   tknnNeigh *d_fb = nullptr;
   int32_t *d_levels = nullptr;
   bool allow_unfinished = false;
+  const float *d_start_radii = nullptr;  // tknnSolveOptions.d_start_radii: per row, or null (one start radius for all)
   int phase = 0;  // tknnSolveOptions.phase: 0 every query, 1 interior queries in the own tree only, 2 boundary queries
 };
 

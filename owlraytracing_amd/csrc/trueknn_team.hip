@@ -49,15 +49,17 @@ namespace {
 constexpr int kTeamBlock = 64;      // one wave per workgroup: LDS, not the block shape, limits residency
 constexpr int kMaxBlocks = 256;     // leaf blocks one packet may need per level (slot fits a byte)
 #ifndef TKNN_MAX_PER_QUERY
-#define TKNN_MAX_PER_QUERY 72
+#define TKNN_MAX_PER_QUERY 72  // (k <= 16)
 #endif
-constexpr int kMaxPerQuery = TKNN_MAX_PER_QUERY;
+// leaf blocks one query may need per level: k <= 16 (one list register per lane) 72 -- lists of the benchmark run to 60 --,
+// larger k 96 (a third of the queries of 10 M uniform points need more than 72 at k = 32 and would be handed over)
+constexpr int max_per_query(int nreg) { return nreg == 1 ? TKNN_MAX_PER_QUERY : 96; }
 #ifndef TKNN_MERGE_AT
 #define TKNN_MERGE_AT 12  // buffered candidates of some team at the end of a group of four blocks that trigger a merge
 #endif
 #ifndef TKNN_TEAM_WAVES
 #define TKNN_TEAM_WAVES 4  // waves per SIMD the packet kernel's register allocation aims at
-#endif  // leaf blocks one query may need per level
+#endif
 constexpr int kTeamStack = 192;     // wide-pyramid stack entries per wave
 constexpr int kQrecStride = 6;      // floats per LDS query record (layout below)
 constexpr int kScanBudget = 16384;  // leaf blocks one packet-level may test against its queries before it is handed over
@@ -67,22 +69,33 @@ constexpr int kMaxStep = 2;          // radius levels one gather may serve (the 
 // passes, so they share one region.  Every KB counts: LDS, not registers, limits residency.
 constexpr int kLdsQrec = 64 * kQrecStride * 4;
 constexpr int kLdsBlk = kMaxBlocks * 4;
-constexpr int kLdsMask = 64 * kMaxPerQuery;  // per-query lists of block slots (bytes)
 constexpr int kLdsCnt = 64 * 2 * 4;  // per query: candidates at the inner level, at the outer level | self << 31
 constexpr int kLdsList = 64 * 4 + 16;  // + the bucket-presence word of the list builder
 constexpr int kLdsStack = kTeamStack * 4;
 constexpr int kLdsShared = (kLdsCnt + kLdsList) > kLdsStack ? (kLdsCnt + kLdsList) : kLdsStack;
-// per team: the block entries of the query it serves, resolved and in visit order (+ 4: a pass
-// prefetches one group of four past the end of a list rounded up to whole groups)
-constexpr int kEntStride = kMaxPerQuery + 4;
-constexpr int kLdsEnt = 4 * kEntStride * 4;
 constexpr int kLdsSharedPadded = (kLdsShared + 15) & ~15;  // the entry lists are read 16 bytes at a time
 // per team (k <= 16): candidates that passed the gate since the last merge into the team's sorted list, as
 // 64-bit (dist, index) keys, and how many there are.  At most 16 when a block is tested, so 32 hold any block.
 constexpr int kCandCap = 32;
-constexpr int kLdsCand = 4 * kCandCap * 8 + 16;
-constexpr int kTeamLds = kLdsQrec + kLdsBlk + kLdsMask + kLdsSharedPadded + kLdsEnt + kLdsCand;
-static_assert(kEntStride % 4 == 0 && (kLdsQrec + kLdsBlk + kLdsMask) % 16 == 0, "entry lists must be 16-byte aligned");
+// LDS per wave, by the number of list registers per lane: query records | block list | per-query block lists |
+// counts, query list / pyramid stack | per-team entry lists | per-team candidate buffers (k <= 16 only)
+template <int NREG>
+struct TeamLayout {
+  static constexpr int kMaxPerQuery = max_per_query(NREG);
+  static constexpr int kLdsMask = 64 * kMaxPerQuery;  // per-query lists of block slots (bytes)
+  // per team: the block entries of the query it serves, resolved and in visit order (+ 4: a pass
+  // prefetches one group of four past the end of a list rounded up to whole groups)
+  static constexpr int kEntStride = kMaxPerQuery + 4;
+  static constexpr int kLdsEnt = 4 * kEntStride * 4;
+  static constexpr int kLdsCand = NREG == 1 ? 4 * kCandCap * 8 + 16 : 0;
+  static constexpr int kOffMask = kLdsQrec + kLdsBlk;
+  static constexpr int kOffShared = kOffMask + kLdsMask;
+  static constexpr int kOffEnt = kOffShared + kLdsSharedPadded;
+  static constexpr int kOffCand = kOffEnt + kLdsEnt;
+  static constexpr int kTeamLds = kOffCand + kLdsCand;
+  static_assert(kEntStride % 4 == 0 && kOffEnt % 16 == 0, "entry lists must be 16-byte aligned");
+  static_assert(kMaxPerQuery <= 96 && kMaxPerQuery / 4 < 32, "list-length buckets of the pass lists are one bit each of a 32-bit word");
+};
 
 // LDS query record: [0..2] q, [3] id, [4] radius of the box the pass works in (outermost level of
 // the step for COUNT, the finishing level for SELECT), [5] packed: #blocks | position of the query's
@@ -99,6 +112,9 @@ struct TeamArgs {
   LbvhView bvh, halo;
   LbvhWideView wide[2];
   float start_radius;
+  // per-query radius schedule (tknnSolveOptions.d_start_radii): per ROW the radius query `row` starts
+  // with, or null -- then every query starts with start_radius, as in the reference (hostCode.cpp:185,325)
+  const float *start_radii;
   int k;
   int max_rounds;
   int allow_unfinished;
@@ -276,9 +292,10 @@ __device__ __forceinline__ bool tie_may_straddle(float d, float r0, float r_last
 // TWO: a COUNT pass that also counts the inner box of a two-level step (a template flag: as a run-time value the
 // compiler kept "m > 1" as a lane mask and re-derived a branch from it for every block)
 template <bool SELECT, bool HALO, int NREG, bool FULL, bool TWO>
-__device__ __forceinline__ void team_pass(const TeamArgs &a, const TeamLds &L, int n_list, float r_inner, int32_t first_slot,
+__device__ __forceinline__ void team_pass(const TeamArgs &a, const TeamLds &L, int n_list, int32_t first_slot,
                                           const LbvhPoint *own_pts, const LbvhPoint *halo_pts, int lane) {
   const int team = lane >> 4, tl = lane & 15;
+  constexpr int kMaxPerQuery = TeamLayout<NREG>::kMaxPerQuery, kEntStride = TeamLayout<NREG>::kEntStride;
   static_assert(!(SELECT && TWO), "only a COUNT pass serves two levels");
   n_list = __builtin_amdgcn_readfirstlane(n_list);  // wave-uniform by construction; says so to the compiler (scalar branches on it)
   [[maybe_unused]] unsigned long long tp[4] = {0, 0, 0, 0};  // TKNN_DIAG_BUILD, flag 128: setup | first group | other groups | epilogue
@@ -302,7 +319,10 @@ __device__ __forceinline__ void team_pass(const TeamArgs &a, const TeamLds &L, i
     const float t_r = rec[4];
     const float t_mg = (fmaxf(fmaxf(fabsf(t_qx), fabsf(t_qy)), fabsf(t_qz)) + 2.0f * t_r) * 4.76837158203125e-07f;  // 2^-21, see above
     const float in_below = t_r - t_mg, in_upto = t_r + t_mg;          // certainly / possibly a candidate
-    const float i0_below = r_inner - t_mg, i0_upto = r_inner + t_mg;  // same for the inner level of a two-level COUNT step
+    // the inner level of a two-level COUNT step: half my outer radius (exact: radii double in fp32).  Not a pass
+    // argument: with a per-query schedule every query has radii of its own.
+    const float r_inner = t_r * 0.5f;
+    const float i0_below = r_inner - t_mg, i0_upto = r_inner + t_mg;
     uint32_t cnt_i0 = 0;  // inner level of a two-level COUNT step (m = levels served by this gather, wave-uniform)
     const int packed = __float_as_int(rec[5]);
     const int my_n = on ? (packed & 0xff) : 0;  // leaf blocks of my team's query
@@ -315,7 +335,6 @@ __device__ __forceinline__ void team_pass(const TeamArgs &a, const TeamLds &L, i
     // (clamped to the last one; teams without a query read block 0 of the own tree and ignore it)
     const uint8_t *mine = L.qblk + qi * kMaxPerQuery;
     const int last = my_n - 1;
-    static_assert(kMaxPerQuery <= 96 && kMaxPerQuery / 4 < 32, "entry registers below are written out for 6 x 16 entries");
     // positions past the end of my list (and teams without a query) name the all-NaN block after
     // the own tree's last block: its points fail every test, so the loop needs no "am I still in
     // my list" check
@@ -626,8 +645,9 @@ __device__ __forceinline__ void team_pass(const TeamArgs &a, const TeamLds &L, i
       if (__ballot(any) != 0ull) {  // rare: does any of them span two rounds?
         const float qmax = fmaxf(fmaxf(fabsf(t_qx), fabsf(t_qy)), fabsf(t_qz));
         any = false;
+        const float q_r0 = a.start_radii ? a.start_radii[a.bvh.prim_id[first_slot + qi]] : a.start_radius;
 #pragma unroll
-        for (int j = 0; j < NREG; j++) any |= tie[j] && tie_may_straddle(__uint_as_float(bd[j]), a.start_radius, t_r, qmax, a.tie_span);
+        for (int j = 0; j < NREG; j++) any |= tie[j] && tie_may_straddle(__uint_as_float(bd[j]), q_r0, t_r, qmax, a.tie_span);
       }
       tied = ((uint32_t)(__ballot(any) >> (team * 16)) & 0xffffu) ? 1u : 0u;
     }
@@ -679,17 +699,19 @@ __global__ void __launch_bounds__(kTeamBlock) __attribute__((amdgpu_waves_per_eu
   const int lane = threadIdx.x & 63;
   const int wid = threadIdx.x >> 6;  // 0 with one wave per workgroup
   const int tl = lane & 15;
-  unsigned char *base = smem + wid * kTeamLds;
+  using Lay = TeamLayout<NREG>;
+  constexpr int kMaxPerQuery = Lay::kMaxPerQuery;
+  unsigned char *base = smem + wid * Lay::kTeamLds;
   float *qrec = (float *)base;
   int32_t *blk = (int32_t *)(base + kLdsQrec);
-  uint8_t *qblk = (uint8_t *)(base + kLdsQrec + kLdsBlk);  // [query][kMaxPerQuery] slots into blk[]
-  uint32_t *qcnt = (uint32_t *)(base + kLdsQrec + kLdsBlk + kLdsMask);
-  int32_t *qlist = (int32_t *)(base + kLdsQrec + kLdsBlk + kLdsMask + kLdsCnt);
-  int32_t *stack = (int32_t *)(base + kLdsQrec + kLdsBlk + kLdsMask);  // shares the counts / query list region
-  int32_t *ent = (int32_t *)(base + kLdsQrec + kLdsBlk + kLdsMask + kLdsSharedPadded);
-  unsigned long long *cand = (unsigned long long *)(base + kLdsQrec + kLdsBlk + kLdsMask + kLdsSharedPadded + kLdsEnt);
-  uint32_t *cand_n = (uint32_t *)(base + kLdsQrec + kLdsBlk + kLdsMask + kLdsSharedPadded + kLdsEnt + 4 * kCandCap * 8);
-  if (lane < 4) cand_n[lane] = 0u;
+  uint8_t *qblk = (uint8_t *)(base + Lay::kOffMask);  // [query][kMaxPerQuery] slots into blk[]
+  uint32_t *qcnt = (uint32_t *)(base + Lay::kOffShared);
+  int32_t *qlist = (int32_t *)(base + Lay::kOffShared + kLdsCnt);
+  int32_t *stack = (int32_t *)(base + Lay::kOffShared);  // shares the counts / query list region
+  int32_t *ent = (int32_t *)(base + Lay::kOffEnt);
+  unsigned long long *cand = (unsigned long long *)(base + Lay::kOffCand);  // (k <= 16 only: zero bytes otherwise, never touched)
+  uint32_t *cand_n = (uint32_t *)(base + Lay::kOffCand + 4 * kCandCap * 8);
+  if (NREG == 1 && lane < 4) cand_n[lane] = 0u;
 
   const LbvhPoint *own_pts = a.bvh.points + tl, *halo_pts = a.halo.points ? a.halo.points + tl : a.bvh.points + tl;
   unsigned long long my_isect_sum = 0, my_levels = 0, my_unfinished = 0, wave_node_tests = 0, wave_point_tests = 0;
@@ -745,6 +767,7 @@ __global__ void __launch_bounds__(kTeamBlock) __attribute__((amdgpu_waves_per_eu
     if (active) q = a.bvh.points[slot];
     const int32_t row = active ? a.bvh.prim_id[slot] : 0;
     float r = a.start_radius;
+    if (a.start_radii && active) r = a.start_radii[row];  // a radius schedule of my own (levels stay common: level t = r0_q * 2^t)
     int level = 0;
     int64_t isect = 0;
     uint32_t prev_others = 0;  // others in my box at the previous level
@@ -767,7 +790,7 @@ __global__ void __launch_bounds__(kTeamBlock) __attribute__((amdgpu_waves_per_eu
       // keeps them and everything derived from them in scalar registers and branches on them without exec masks)
       level = __builtin_amdgcn_readfirstlane(level);
       step = __builtin_amdgcn_readfirstlane(step);
-      r = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(r)));
+      if (!a.start_radii) r = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(r)));
       int m = step < 1 ? 1 : (step > kMaxStep ? kMaxStep : step);
       if (level + m > a.max_rounds) m = a.max_rounds - level;
       const float r_in0 = r;                        // radius of the inner level of a two-level step
@@ -1007,9 +1030,9 @@ __global__ void __launch_bounds__(kTeamBlock) __attribute__((amdgpu_waves_per_eu
         const int n_count = build_qlist(count_first);
         if (!(TKNN_DIAG_BUILD && (a.diag & 4))) {
           if (m > 1)
-            team_pass<false, HALO, NREG, false, true>(a, L, n_count, r_in0, g * 64, own_pts, halo_pts, lane);
+            team_pass<false, HALO, NREG, false, true>(a, L, n_count, g * 64, own_pts, halo_pts, lane);
           else
-            team_pass<false, HALO, NREG, false, false>(a, L, n_count, r_in0, g * 64, own_pts, halo_pts, lane);
+            team_pass<false, HALO, NREG, false, false>(a, L, n_count, g * 64, own_pts, halo_pts, lane);
         }
         t_wave_sync();
       }
@@ -1032,7 +1055,7 @@ __global__ void __launch_bounds__(kTeamBlock) __attribute__((amdgpu_waves_per_eu
       {
         t_wave_sync();
         const int n_select = build_qlist(select_now);
-        if (!(TKNN_DIAG_BUILD && (a.diag & 2))) team_pass<true, HALO, NREG, FULL, false>(a, L, n_select, r_in0, g * 64, own_pts, halo_pts, lane);
+        if (!(TKNN_DIAG_BUILD && (a.diag & 2))) team_pass<true, HALO, NREG, FULL, false>(a, L, n_select, g * 64, own_pts, halo_pts, lane);
         t_wave_sync();
       }
       PHASE_END(3);
@@ -1163,7 +1186,8 @@ __global__ void __launch_bounds__(kTeamBlock) team_walk_kernel(TeamArgs a, const
     const int32_t row = a.bvh.prim_id[slot];
     int level = has_q ? a.next_level[slot] : 0;
     int64_t isect = has_q ? a.isect_sorted[slot] : 0;
-    float r = a.start_radius;
+    const float q_r0 = a.start_radii ? a.start_radii[row] : a.start_radius;  // per-query schedule, if asked for
+    float r = q_r0;
     for (int i = 0; i < level; i++) r = r * 2.0f;
     bool active = has_q;
     while (__ballot(active) != 0ull) {  // one radius level for every team that is still at work
@@ -1351,7 +1375,7 @@ __global__ void __launch_bounds__(kTeamBlock) team_walk_kernel(TeamArgs a, const
             if (reg > 0) before |= t_dpp<0x121>(bd[reg - 1]) & (tl == 0 ? 0xffffffffu : 0u);
             bool t = ((reg > 0) | (tl >= 1)) & (16 * reg + tl <= a.k) & (bd[reg] == before);
             if (reg == NREG - 1 && full) t |= (tl == 15) & (left_out == bd[reg]);
-            tie |= t && tie_may_straddle(__uint_as_float(bd[reg]), a.start_radius, r, qmax, a.tie_span);
+            tie |= t && tie_may_straddle(__uint_as_float(bd[reg]), q_r0, r, qmax, a.tie_span);
           }
           const bool tied = ((uint32_t)(__ballot(tie) >> (team * 16)) & 0xffffu) != 0u;
           if (tl == 0) {
@@ -1468,14 +1492,15 @@ __global__ void __launch_bounds__(kTeamBlock) tie_fix_kernel(TeamArgs a, const i
     const int32_t row = a.bvh.prim_id[slot];
     active = active && a.tie[slot] != 0;  // a listed slot that is not flagged (any more) keeps its row
     const int level = active ? (int)a.tie[slot] - 1 : 0;
-    float r = a.start_radius;
+    const float q_r0 = a.start_radii ? a.start_radii[row] : a.start_radius;
+    float r = q_r0;
     for (int i = 0; i < level; i++) r = r * 2.0f;
     const float mg = (fmaxf(fmaxf(fabsf(q.x), fabsf(q.y)), fabsf(q.z)) + 2.0f * r) * 4.76837158203125e-07f;  // 2^-21, as in team_walk_kernel
     const float in_below = r - mg, in_upto = r + mg;
     const float rl = r + 2.0f * mg;
     // key word between distance and index: the level at which the candidate was first one
     auto first_level = [&](const LbvhPoint &p) -> uint32_t {
-      float rr = a.start_radius;
+      float rr = q_r0;
       for (int l = 0; l < level; l++) {
         if (knn_in_box(p.x, p.y, p.z, rr, q.x, q.y, q.z)) return (uint32_t)l;
         rr = rr * 2.0f;
@@ -1646,6 +1671,7 @@ void Engine::launch_tie_fix(const SolveArgs &sa, const int32_t *slots, int32_t n
   a.wide[0] = bvh_.wide_view();
   if (halo_count() > 0) a.wide[1] = halo_.wide_view();
   a.start_radius = sa.start_radius;
+  a.start_radii = sa.d_start_radii;
   a.k = sa.k;
   a.out_idx = sa.d_idx;
   a.out_dist = sa.d_dist;
@@ -1757,10 +1783,11 @@ bool Engine::solve_team(const SolveArgs &sa, tknnSolveInfo *info, hipStream_t s)
   else
     std::memset(&a.wide[1], 0, sizeof(a.wide[1]));
   a.start_radius = sa.start_radius;
+  a.start_radii = sa.d_start_radii;
   a.k = sa.k;
   a.max_rounds = sa.max_rounds;
   a.allow_unfinished = sa.allow_unfinished ? 1 : 0;
-  a.first_step = first_step_estimate(sa);
+  a.first_step = sa.d_start_radii ? 1 : first_step_estimate(sa);  // (the estimate is from ONE start radius and the mean density)
   {
     // axes along which the built points differ at all (2-D inputs carry z = 0, hostCode.cpp:115-118);
     // a halo tree may hold anything
@@ -1791,7 +1818,9 @@ bool Engine::solve_team(const SolveArgs &sa, tknnSolveInfo *info, hipStream_t s)
   hipDeviceProp_t prop;
   OWLMI_HIP(hipGetDeviceProperties(&prop, device_));
   int per_cu = 2;
-  const size_t lds = (size_t)kTeamBlock / 64 * kTeamLds;
+  const int nreg_for_lds = sa.k <= 16 ? 1 : (sa.k <= 32 ? 2 : 4);
+  const size_t lds = (size_t)kTeamBlock / 64 *
+                     (size_t)(nreg_for_lds == 1 ? TeamLayout<1>::kTeamLds : (nreg_for_lds == 2 ? TeamLayout<2>::kTeamLds : TeamLayout<4>::kTeamLds));
   const bool with_halo = halo_count() > 0;
   const int nreg = sa.k <= 16 ? 1 : (sa.k <= 32 ? 2 : 4);  // list registers per lane
   const int nreg_at = nreg == 4 ? 2 : nreg - 1;           // index into the tables of instantiations
@@ -1957,7 +1986,8 @@ bool Engine::solve_team(const SolveArgs &sa, tknnSolveInfo *info, hipStream_t s)
     const char *force = getenv("TKNN_TEAM_TAIL");  // "walk" / "lane" / "wave": tests and measurements only
     // (k > 32: the team walk beats the wave kernel's 64-entry register lists on any share, 10 M uniform
     // points from level 0: 137 against 223 ms at k = 50)
-    const bool by_wave = wave_kernel_available() && (force ? !strcmp(force, "wave") : (handed * 4ull >= (unsigned long long)n && sa.k <= 32));
+    const bool by_wave = !sa.d_start_radii && wave_kernel_available() &&
+                         (force ? !strcmp(force, "wave") : (handed * 4ull >= (unsigned long long)n && sa.k <= 32));
     const bool by_walk = !by_wave && !(force && !strcmp(force, "lane"));
     const int first_handover_level = (int)h_counters_[9];
     if (by_wave) {
@@ -2010,6 +2040,8 @@ bool Engine::solve_team(const SolveArgs &sa, tknnSolveInfo *info, hipStream_t s)
       tail.dominant_kernel_launches = 1;
       const unsigned long long left = h_counters_[8];  // stack exhausted: state untouched, lane rounds take them
       if (tail.unfinished && !sa.allow_unfinished) throw RoundsExceeded{};
+      if (left && sa.d_start_radii)
+        throw ArgError{TKNN_E_UNSUPPORTED, "per-query start radii: a query's candidate walk outgrew the team walk's stack (the lane rounds that take over otherwise use one radius per launch)"};
       if (left) {
         tknnSolveInfo rest;
         std::memset(&rest, 0, sizeof rest);
@@ -2024,6 +2056,7 @@ bool Engine::solve_team(const SolveArgs &sa, tknnSolveInfo *info, hipStream_t s)
         tail.dominant_kernel_launches += rest.dominant_kernel_launches;
       }
     } else {
+      if (sa.d_start_radii) throw ArgError{TKNN_E_UNSUPPORTED, "per-query start radii are served by the team kernels only (TKNN_TEAM_TAIL=lane)"};
       continue_lane(sa, first_handover_level, &tail, s);
     }
     if (getenv("TKNN_VERBOSE"))

@@ -121,12 +121,14 @@ class TrueKNN:
     supports_phases = True  # solve(phase=1 | 2): interior / boundary queries of a tile (tknnSolveOptions.phase)
 
     def solve(self, k, start_radius, kernel=_lib.KERNEL_AUTO, max_rounds=64, want_fb=False,
-              out=None, want_levels=False, allow_unfinished=False, phase=0, stream=None):
+              out=None, want_levels=False, allow_unfinished=False, phase=0, stream=None, start_radii=None):
         """Returns dict(idx (n,k) int32, dist (n,k) f32, intersections (n,) int64[, fb (n*k*24,) uint8])
         as CUDA tensors plus ``info``.  ``out`` may carry preallocated tensors of those names.
         ``phase`` 1 / 2: only the interior / boundary queries marked by the last ``halo_select`` (sharded use);
         ``stream``: a torch.cuda.Stream to launch on instead of the current one (a phase-1 solve runs on a
-        stream and host thread of its own beside the halo exchange)."""
+        stream and host thread of its own beside the halo exchange).
+        ``start_radii``: (n,) float32, a start radius per query (row) instead of ``start_radius`` for all -- the opt-in
+        per-query radius schedule (tknnSolveOptions.d_start_radii)."""
         torch = self._torch
         n = self.n
         out = dict(out or {})
@@ -149,6 +151,12 @@ class TrueKNN:
             opt.k, opt.start_radius, opt.kernel = int(k), float(start_radius), int(kernel)
             opt.max_rounds, opt.allow_unfinished = int(max_rounds), int(bool(allow_unfinished))
             opt.phase = int(phase)
+            radii = None
+            if start_radii is not None:
+                radii = torch.as_tensor(start_radii, dtype=torch.float32, device=self.device).contiguous()
+                if radii.shape != (n,):
+                    raise ValueError("start_radii must have one entry per point")
+                opt.d_start_radii = radii.data_ptr()
             for field, name in (("d_idx", "idx"), ("d_dist", "dist"), ("d_intersections", "intersections"),
                                 ("d_fb", "fb"), ("d_levels", "levels")):
                 p = ptr(name)

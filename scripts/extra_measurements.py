@@ -40,7 +40,34 @@ def timed_solve(name, pts, k, r0, kernels=(3, 2, 1)):
 
 
 def main():
-    which = sys.argv[1:] or ["gmm", "taxi", "dbscan", "sample"]
+    which = sys.argv[1:] or ["gmm", "taxi", "ksweep", "sizes", "dbscan", "dbscan_auto", "sample"]
+    if "ksweep" in which:  # BASELINE config 2's set at other k (team kernels: 1, 2 or 4 list registers per lane)
+        pts = datasets.uniform3d(10_000_000, seed=0)
+        for k in (5, 16, 32, 50, 64):
+            timed_solve("trueknn_uniform3d_10M_k%d" % k, pts, k, datasets.start_radius(len(pts), k), kernels=(3,))
+        del pts
+    if "sizes" in which:  # config 4's whole 100 M-point set on ONE GPU
+        for n in (50_000_000, 100_000_000):
+            pts = datasets.uniform3d_counter(0, n, seed=0)
+            timed_solve("trueknn_uniform3d_%dM_k10" % (n // 1_000_000), pts, 10, datasets.start_radius(n, 10), kernels=(3,))
+            del pts
+    if "dbscan_auto" in which:  # config 5's point set (50 M heavy-tailed 2-D points, 5 % duplicates) on ONE GPU, eps auto-grown
+        pts = datasets.pad_to_3d(datasets.taxi_like2d(50_000_000, components=256, seed=2))
+        eng = TrueKNN()
+        b = eng.build(torch.from_numpy(pts).cuda())
+        for eps0, max_noise in ((0.00005, 0.05), (0.00005, 0.01)):
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            r = eng.dbscan_auto(eps0, 4, max_noise)
+            torch.cuda.synchronize()
+            w = (time.perf_counter() - t) * 1e3
+            i = r["info"]
+            out["dbscan_auto_taxi2d_50M_minpts4_eps0_%g_noise_%g" % (eps0, max_noise)] = {
+                "wall_ms": w, "build_ms": b["build_ms"], "rounds": i["rounds"], "eps": i["eps"], "noise": i["noise"], "clusters": i["clusters"],
+                "probe_rounds_ms": i["probe_ms"], "final_clustering_ms": i["solve_ms"]}
+            print("dbscan_auto", out["dbscan_auto_taxi2d_50M_minpts4_eps0_%g_noise_%g" % (eps0, max_noise)], flush=True)
+        eng.close()
+        del pts
     if "gmm" in which:
         pts = datasets.gaussian_mixture3d(10_000_000, components=64, sigma=0.02, seed=1)
         timed_solve("trueknn_gmm3d_10M_k10", pts, 10, 0.0005)
@@ -60,7 +87,9 @@ def main():
             lab = r["labels"]
             out["dbscan_gmm3d_%d_eps0.01_minpts4" % n] = {
                 "wall_ms": w, "device_ms": r["info"]["solve_ms"], "clusters": r["info"]["clusters"],
-                "noise": int((lab < 0).sum()), "core": int(r["core"].sum())}
+                "noise": int((lab < 0).sum()), "core": int(r["core"].sum()),
+                "kernels_ms": {"core_flags": r["info"]["core_ms"], "unions": r["info"]["union_ms"], "labels": r["info"]["label_ms"]},
+                "node_tests": r["info"]["node_tests"], "point_tests": r["info"]["point_tests"]}
             print("dbscan", n, out["dbscan_gmm3d_%d_eps0.01_minpts4" % n], flush=True)
             eng.close()
     if "sample" in which:

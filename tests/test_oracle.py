@@ -248,3 +248,20 @@ def test_tie_flag_bound_never_misses_a_cross_round_tie():
                 straddling += 1
                 assert may_straddle(dist[0], r0, r_last, qmax, span), (q, pts, r0, firsts)
     assert straddling > 500 and checked == 8000
+
+
+def test_per_query_radius_statement_is_the_reference_loop_per_query():
+    """oracle.trueknn_per_query: with one radius for all it IS the reference solve; with classes of radii every class
+    equals a plain solve of that class's queries (rows never depend on other rows)."""
+    pts = datasets.uniform3d(3000, seed=9)
+    k = 5
+    plain = oracle.trueknn(pts, k, 0.02)
+    same = oracle.trueknn_per_query(pts, k, np.full(len(pts), 0.02, np.float32))
+    assert np.array_equal(same["idx"], plain["idx"]) and np.array_equal(same["dist"], plain["dist"])
+    assert np.array_equal(same["intersections"], plain["intersections"]) and same["rounds"] == plain["rounds"]
+    radii = np.where(np.arange(len(pts)) % 2 == 0, np.float32(0.01), np.float32(0.08)).astype(np.float32)
+    mixed = oracle.trueknn_per_query(pts, k, radii)
+    small, large = oracle.trueknn(pts, k, 0.01), oracle.trueknn(pts, k, float(np.float32(0.08)))
+    even = np.arange(len(pts)) % 2 == 0
+    assert np.array_equal(mixed["idx"][even], small["idx"][even]) and np.array_equal(mixed["idx"][~even], large["idx"][~even])
+    assert np.array_equal(mixed["intersections"][~even], large["intersections"][~even])

@@ -365,3 +365,49 @@ def test_exact_repair_gives_bruteforce_knn():
         changed = int((before != r["idx"]).any(dim=1).sum())
         assert 0 < changed <= fixed < n  # a sizeable share of reference rows is not exact kNN
         eng.close()
+
+
+@pytest.mark.gpu
+def test_per_query_radius_schedule():
+    """tknnSolveOptions.d_start_radii (opt-in): every query doubles from a start radius of its own.  Rows,
+    intersection counts and the number of rounds equal the checker's per-query statement (each query run through the
+    reference's loop from its own radius): random radius classes on uniform points, radii from the local density on a
+    clustered set (fewer rounds than one global radius needs), and a set full of exact-distance ties."""
+    import torch
+
+    from owlraytracing_amd import _lib
+    from owlraytracing_amd.trueknn import TrueKNN
+    eng = TrueKNN()
+    rng = np.random.default_rng(77)
+    cases = []
+    pts = datasets.uniform3d(60_000, seed=41)
+    cases.append(("uniform, four random classes", pts, 10, rng.choice(np.float32([0.004, 0.008, 0.016, 0.05]), len(pts))))
+    pts = datasets.gaussian_mixture3d(50_000, components=7, sigma=0.03, seed=42)
+    # a density guess per point: distance to the 3rd nearest of a thinned copy, clipped and rounded to a few values
+    from scipy.spatial import cKDTree
+    d3 = cKDTree(pts[::8].astype(np.float64)).query(pts.astype(np.float64), k=3)[0][:, 2]
+    radii = np.float32(0.002) * np.float32(2.0) ** np.clip(np.round(np.log2(np.maximum(d3, 1e-6) / 0.002)), 0, 5).astype(np.float32)
+    cases.append(("clustered, radii from the local density", pts, 8, radii.astype(np.float32)))
+    lattice = np.stack(np.meshgrid(*[np.arange(14, dtype=np.float32) * np.float32(0.125)] * 3, indexing="ij"), -1).reshape(-1, 3)
+    cases.append(("lattice (ties), two classes", lattice, 6, np.where(np.arange(len(lattice)) % 3 == 0, np.float32(0.07), np.float32(0.13)).astype(np.float32)))
+    for name, pts, k, radii in cases:
+        ref = oracle.trueknn_per_query(pts, k, radii)
+        eng.build(pts)
+        got = eng.solve(k, 1.0, start_radii=torch.from_numpy(radii), kernel=_lib.KERNEL_TEAM)
+        assert_rows_equal(got["idx"].cpu().numpy(), got["dist"].cpu().numpy(), ref["idx"], ref["dist"])
+        assert np.array_equal(got["intersections"].cpu().numpy(), ref["intersections"]), name
+        assert got["info"]["rounds"] == ref["rounds"], name
+        auto = eng.solve(k, 1.0, start_radii=torch.from_numpy(radii))  # AUTO resolves to the team kernels
+        assert np.array_equal(auto["idx"].cpu().numpy(), got["idx"].cpu().numpy())
+    # one global radius is the special case of equal radii
+    pts = cases[0][1]
+    eng.build(pts)
+    a = eng.solve(10, 0.01)
+    b = eng.solve(10, 123.0, start_radii=torch.full((len(pts),), 0.01))
+    assert np.array_equal(a["idx"].cpu().numpy(), b["idx"].cpu().numpy()) and np.array_equal(a["dist"].cpu().numpy(), b["dist"].cpu().numpy())
+    assert np.array_equal(a["intersections"].cpu().numpy(), b["intersections"].cpu().numpy())
+    # not served by the other kernels
+    for kern in (_lib.KERNEL_LANE, _lib.KERNEL_WAVE):
+        with pytest.raises(_lib.TknnError):
+            eng.solve(10, 0.01, start_radii=torch.full((len(pts),), 0.01), kernel=kern)
+    eng.close()

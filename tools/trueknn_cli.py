@@ -24,7 +24,7 @@ def main():
     ap.add_argument("start_radius")
     ap.add_argument("k", type=int)
     ap.add_argument("timefile")
-    ap.add_argument("--out", default=None, help="write idx/dist/intersections as .npz")
+    ap.add_argument("--out", default=None, help="write idx/dist/intersections/levels as .npz (tools/compare_reference_dump.py --rows reads it)")
     ap.add_argument("--kernel", type=int, default=0)
     a = ap.parse_args()
 
@@ -38,7 +38,7 @@ def main():
     eng = TrueKNN()
     b = eng.build(pts)
     print("Build time: %g seconds." % (b["build_ms"] / 1e3))
-    r = eng.solve(a.k, r0, kernel=a.kernel)
+    r = eng.solve(a.k, r0, kernel=a.kernel, want_levels=True)
     info = r["info"]
     print("Rounds: %d  start radius %g  final radius %g" % (info["rounds"], r0, info["final_radius"]))
     print("True KNN time: %g seconds." % (info["solve_ms"] / 1e3))
@@ -48,7 +48,7 @@ def main():
         fh.write("%g\n" % tot)
     if a.out:
         np.savez(a.out, idx=r["idx"].cpu().numpy(), dist=r["dist"].cpu().numpy(),
-                 intersections=r["intersections"].cpu().numpy())
+                 intersections=r["intersections"].cpu().numpy(), levels=r["levels"].cpu().numpy())
     eng.close()
 
 
