@@ -57,6 +57,9 @@ constexpr int max_per_query(int nreg) { return nreg == 1 ? TKNN_MAX_PER_QUERY : 
 #ifndef TKNN_MERGE_AT
 #define TKNN_MERGE_AT 12  // buffered candidates of some team at the end of a group of four blocks that trigger a merge
 #endif
+#ifndef TKNN_SORT_FIRST
+#define TKNN_SORT_FIRST 1  // k <= 16: 1 = sort the query's own block on the spot instead of buffering its candidates
+#endif
 #ifndef TKNN_TEAM_WAVES
 #define TKNN_TEAM_WAVES 4  // waves per SIMD the packet kernel's register allocation aims at
 #endif
@@ -464,7 +467,7 @@ __device__ __forceinline__ void team_pass(const TeamArgs &a, const TeamLds &L, i
         in_m = __ballot(t <= below) | (__ballot(t <= upto) & __ballot(knn_in_box(p.x, p.y, p.z, radius, t_qx, t_qy, t_qz)));
       return in_m;
     };
-    auto process = [&](const LbvhPoint &p) {
+    auto process = [&](const LbvhPoint &p, bool own_block = false) {
       const float dx = p.x - t_qx, dy = p.y - t_qy, dz = p.z - t_qz;
       // NaN only if all three are (sentinels; lbvh.hip turns a point with any NaN coordinate into one)
       const float t = fmaxf(fmaxf(fabsf(dx), fabsf(dy)), fabsf(dz));
@@ -476,6 +479,7 @@ __device__ __forceinline__ void team_pass(const TeamArgs &a, const TeamLds &L, i
         // candidates that pass the gate.  The query itself sits in its own block, which SELECT visits
         // first and settles in the sorted first step, so no block seen here can hold it (ids are unique).
         unsigned long long pm = in_m & __ballot(d2 <= tau2);
+        if (own_block) pm &= __ballot(p.id != t_qid);  // deviceCode.cu:103: a query is no neighbour of itself (ids are unique: only its own block holds it)
         if (TKNN_DIAG_BUILD && (a.diag & 1)) pm = 0;
         if (NREG == 1) {
           if (pm) {
@@ -593,10 +597,16 @@ __device__ __forceinline__ void team_pass(const TeamArgs &a, const TeamLds &L, i
     }
     for (int it = 0; it < steps; it += 4) {
       const t_int4 g = my_groups[(it >> 2) + 1];  // entries it+4 .. it+7
-      if (SELECT && it == 0)
-        sort_first(unpack(b0));
-      else
+      if (SELECT && it == 0) {
+        // the query's own block meets an empty list.  k <= 16: its candidates simply are the first into the team's
+        // buffer, sorted by the first merge; larger k: sorted on the spot (sort_first), the other blocks insert one by one
+        if (NREG == 1 && TKNN_SORT_FIRST == 0)
+          process(unpack(b0), true);
+        else
+          sort_first(unpack(b0));
+      } else {
         process(unpack(b0));
+      }
       b0 = fetch(g.x);
       process(unpack(b1));
       b1 = fetch(g.y);
@@ -800,7 +810,7 @@ __global__ void __launch_bounds__(kTeamBlock) __attribute__((amdgpu_waves_per_eu
       float lo_x = INFINITY, lo_y = INFINITY, lo_z = INFINITY, hi_x = -INFINITY, hi_y = -INFINITY, hi_z = -INFINITY;
       {
         const float mg = (fmaxf(fmaxf(fabsf(q.x), fabsf(q.y)), fabsf(q.z)) + 2.0f * r_out) * 4.76837158203125e-07f;  // 2^-21
-        if (active) {
+        if (active && q.x == q.x) {  // (a NaN query -- lbvh.hip makes every coordinate NaN -- keeps the empty box: it needs no block)
           lo_x = (q.x - r_out) - 2.0f * mg;
           lo_y = (q.y - r_out) - 2.0f * mg;
           lo_z = (q.z - r_out) - 2.0f * mg;
@@ -832,13 +842,40 @@ __global__ void __launch_bounds__(kTeamBlock) __attribute__((amdgpu_waves_per_eu
           s_hi_z[j] = t_bcast(r_hi_z, 16 * j);
         }
       }
+      // Box against box as arithmetic, not as six compares and five mask operations: the largest separation along
+      // any axis, max_a max(b.lo_a - hi_a, lo_a - b.hi_a), is <= 0 exactly when the closed boxes meet (block boxes
+      // are never NaN, empty ones are (+inf, -inf): lbvh.hip).  Plain subtractions and maxima issue at twice the
+      // rate of compares on gfx950 and leave the CU's scalar pipe alone (scripts/microbench/issue_rate.hip).
+      auto separation = [](float b_lo_x, float b_lo_y, float b_lo_z, float b_hi_x, float b_hi_y, float b_hi_z, float q_lo_x, float q_lo_y,
+                           float q_lo_z, float q_hi_x, float q_hi_y, float q_hi_z) -> float {
+        const float sx = fmaxf(b_lo_x - q_hi_x, q_lo_x - b_hi_x), sy = fmaxf(b_lo_y - q_hi_y, q_lo_y - b_hi_y),
+                    sz = fmaxf(b_lo_z - q_hi_z, q_lo_z - b_hi_z);
+        return fmaxf(fmaxf(sx, sy), sz);
+      };
       auto overlaps_packet = [&](const LbvhBox &bx) -> bool {
-        bool any = false;
+        float best = INFINITY;
 #pragma unroll
         for (int j = 0; j < 4; j++)
-          any |= (bx.lo[0] <= s_hi_x[j]) & (bx.hi[0] >= s_lo_x[j]) & (bx.lo[1] <= s_hi_y[j]) & (bx.hi[1] >= s_lo_y[j]) &
-                 (bx.lo[2] <= s_hi_z[j]) & (bx.hi[2] >= s_lo_z[j]);
-        return any;
+          best = fminf(best, separation(bx.lo[0], bx.lo[1], bx.lo[2], bx.hi[0], bx.hi[1], bx.hi[2], s_lo_x[j], s_lo_y[j], s_lo_z[j], s_hi_x[j],
+                                        s_hi_y[j], s_hi_z[j]));
+        return best <= 0.f;
+      };
+      // The 64 child boxes of the wide node in hand, lane = child, go to LDS (the passes' entry lists are dead
+      // during the gather) so that a surviving child's box reaches all 64 query lanes by three broadcast reads
+      // instead of six v_readlane.
+      float *node_boxes = (float *)ent;
+      static_assert(64 * 6 * 4 <= Lay::kLdsEnt + Lay::kLdsCand, "the gather's child boxes borrow the entry lists' LDS");
+      auto stash_boxes = [&](const LbvhBox &bx) {
+        float2 *dst = (float2 *)(node_boxes + 6 * lane);
+        dst[0] = make_float2(bx.lo[0], bx.lo[1]);
+        dst[1] = make_float2(bx.lo[2], bx.hi[0]);
+        dst[2] = make_float2(bx.hi[1], bx.hi[2]);
+        t_wave_sync();
+      };
+      auto needed_by_me = [&](int src) -> bool {  // does the child in lane `src` meet MY query box?
+        const float2 *b = (const float2 *)(node_boxes + 6 * src);
+        const float2 b0 = b[0], b1 = b[1], b2 = b[2];
+        return separation(b0.x, b0.y, b1.x, b1.y, b2.x, b2.y, lo_x, lo_y, lo_z, hi_x, hi_y, hi_z) <= 0.f;
       };
 
       PHASE_END(0);
@@ -887,14 +924,11 @@ __global__ void __launch_bounds__(kTeamBlock) __attribute__((amdgpu_waves_per_eu
               // overlapped.  Nodes are popped in descending Morton order and taken here from the
               // highest lane down, so filling the list downwards keeps it ascending in memory.
               unsigned long long rest = om;
+              if (rest) stash_boxes(bx);
               while (rest) {
                 const int src = 63 - __builtin_clzll(rest);
                 rest &= ~(1ull << src);
-                const float b_lo_x = t_bcast(bx.lo[0], src), b_lo_y = t_bcast(bx.lo[1], src), b_lo_z = t_bcast(bx.lo[2], src);
-                const float b_hi_x = t_bcast(bx.hi[0], src), b_hi_y = t_bcast(bx.hi[1], src), b_hi_z = t_bcast(bx.hi[2], src);
-                const bool need = (b_lo_x <= hi_x) & (b_hi_x >= lo_x) & (b_lo_y <= hi_y) & (b_hi_y >= lo_y) &
-                                  (b_lo_z <= hi_z) & (b_hi_z >= lo_z);
-                if (__ballot(need) == 0ull) continue;
+                if (__ballot(needed_by_me(src)) == 0ull) continue;
                 if (lane == 0) stack[kTeamStack - 1 - nleaf] = (lvl << 26) | (first_child + src);
                 nleaf++;
               }
@@ -930,13 +964,11 @@ __global__ void __launch_bounds__(kTeamBlock) __attribute__((amdgpu_waves_per_eu
               break;
             }
             // leaf blocks: which of my 64 queries need block c?  (lanes = queries, box by v_readlane)
+            if (om) stash_boxes(bx);
             while (om) {
               const int src = __ffsll((long long)om) - 1;
               om &= om - 1;
-              const float b_lo_x = t_bcast(bx.lo[0], src), b_lo_y = t_bcast(bx.lo[1], src), b_lo_z = t_bcast(bx.lo[2], src);
-              const float b_hi_x = t_bcast(bx.hi[0], src), b_hi_y = t_bcast(bx.hi[1], src), b_hi_z = t_bcast(bx.hi[2], src);
-              bool need = (b_lo_x <= hi_x) & (b_hi_x >= lo_x) & (b_lo_y <= hi_y) & (b_hi_y >= lo_y) &
-                          (b_lo_z <= hi_z) & (b_hi_z >= lo_z);
+              bool need = needed_by_me(src);
               if (TKNN_DIAG_BUILD && (a.diag & 8)) need = false;
               if (__ballot(need) == 0ull) continue;
               if (nb >= kMaxBlocks) {
