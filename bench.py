@@ -118,7 +118,7 @@ def committed_profile(kernel_name, n_local, k):
         return None, "profiles/hbm_traffic.json unreadable: %s" % e
     if not rec:
         return None, "no PMC record for this kernel and size"
-    have, want = rec.get("source_sha16"), _lib.source_fingerprint()
+    have, want = rec.get("source_sha16"), _lib.source_fingerprint(kernel_name)
     if have != want:
         return None, "the committed PMC record was taken on other kernel sources (%s, these are %s): re-run scripts/profile_gpu.sh" % (have, want)
     return rec, None

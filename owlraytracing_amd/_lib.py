@@ -146,9 +146,18 @@ def check(rc):
         raise TknnError(rc, (load().tknnLastError() or b"").decode())
 
 
-def source_fingerprint():
-    """16 hex digits naming the native sources the library is built from (csrc/ and include/): what a committed
-    rocprofv3 record must carry for bench.py to attach it to a run (profiles/hbm_traffic.json)."""
+# native sources a kernel's code does NOT depend on, by kernel-name prefix: a committed profile of the packet kernel stays
+# valid when only the clustering kernels change, and the other way round
+_NOT_IN = {
+    "team_": ("dbscan.hip", "halo_select.hip", "owl_runtime.cpp"),
+    "db_": ("trueknn_team.hip", "trueknn_wave.hip", "halo_select.hip", "owl_runtime.cpp"),
+}
+
+
+def source_fingerprint(kernel=None):
+    """16 hex digits naming the native sources the library -- or, with `kernel`, that kernel -- is built from (csrc/ and
+    include/owlknn.h, include/owl/lbvh_device.h; without `kernel` also the other owl headers): what a committed rocprofv3 record must carry for bench.py
+    to attach it to a run (profiles/hbm_traffic.json)."""
     import glob
     import hashlib
 
@@ -156,10 +165,14 @@ def source_fingerprint():
     files = sorted(glob.glob(os.path.join(_HERE, "csrc", "*.hip")) + glob.glob(os.path.join(_HERE, "csrc", "*.h"))
                    + glob.glob(os.path.join(_HERE, "csrc", "*.cpp")) + glob.glob(os.path.join(_HERE, "csrc", "Makefile"))
                    + glob.glob(os.path.join(root, "include", "**", "*.h"), recursive=True))
+    if kernel is not None:
+        skip = next((v for k, v in _NOT_IN.items() if kernel.startswith(k)), ())
+        owl_headers = os.path.join(root, "include", "owl") + os.sep
+        files = [f for f in files if os.path.basename(f) not in skip
+                 and (not f.startswith(owl_headers) or os.path.basename(f) == "lbvh_device.h")]  # the tree's device layout
     h = hashlib.sha256()
     for f in files:
         h.update(os.path.relpath(f, root).encode())
         with open(f, "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()[:16]
-

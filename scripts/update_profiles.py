@@ -47,7 +47,7 @@ def main():
     n_local = cfg["n_points_total"] // max(b.get("n_gpus", 1), 1)
     key = "%s:n=%d:k=%d" % (kernel, n_local, cfg.get("k", cfg.get("min_pts", 0)))
     rec = {
-        "source_sha16": _lib.source_fingerprint(),
+        "source_sha16": _lib.source_fingerprint(kernel),
         "bytes_per_launch": int((2 * fetch_kb + write_kb) * 1024),
         "FETCH_SIZE_KB_per_launch": fetch_kb,
         "WRITE_SIZE_KB_per_launch": write_kb,
