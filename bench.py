@@ -450,19 +450,24 @@ def dbscan_line(args, info, infos, value, ms_per_step, n_total, n_local, world, 
     }
     if sharded:
         # the sharded driver reports clusters / rounds / halo only; the per-kernel figures are the tiles' own
-        line["roofline"] = {"bound": "hbm", "kernel": "db_union_kernel", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        line["roofline"] = {"bound": "hbm", "kernel": "db_group_union_kernel", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                             "frac": None, "traffic": None, "note": "per-kernel counters are reported by the single-GPU run"}
         return line
     # the dominant traversal kernel of the call, by its own HIP-event time
-    names = {"core_ms": ("db_core_kernel", "core_point_tests", 1), "union_ms": ("db_union_kernel", "union_point_tests", 0),
+    names = {"core_ms": ("db_core_kernel", "core_point_tests", 1), "union_ms": ("db_group_union_kernel", "union_point_tests", 0),
              "label_ms": ("db_label_kernel", "label_point_tests", 4)}
     mean = {nm: float(np.mean([i[nm] for i in infos])) for nm in names}
     dom = max(mean, key=mean.get)
     kernel_name, tests_key, out_bytes = names[dom]
+    launches = max(int(info.get("union_launches", 1)), 1) if dom == "union_ms" else 1
     # SURVEY 8(d) carried over to DBSCAN: 12 B per point whose distance to a query is computed (the query's own
-    # 12 B once per traversal) + what the kernel writes per point (core flag / nothing / label)
-    alg_bytes = 12 * int(info[tests_key]) + 12 * n_local + out_bytes * n_local
-    achieved = alg_bytes / (mean[dom] * 1e-3) / 1e9
+    # 12 B once per traversal) + what the kernel writes per point (core flag / nothing / label); the union kernel
+    # walks once per packet of 64 groups, not per point: 32 B per node box it looks at + 32 B per group it serves
+    if dom == "union_ms":
+        alg_bytes = (32 * int(info["union_node_tests"]) + 12 * int(info[tests_key]) + 32 * int(info["groups"]) * launches) // launches
+    else:
+        alg_bytes = 12 * int(info[tests_key]) + 12 * n_local + out_bytes * n_local
+    achieved = alg_bytes / (mean[dom] / launches * 1e-3) / 1e9
     line["roofline"] = {
         "bound": "hbm",
         "kernel": kernel_name,
@@ -472,9 +477,10 @@ def dbscan_line(args, info, infos, value, ms_per_step, n_total, n_local, world, 
         "frac": achieved / HBM_PEAK_GBS,
         "traffic": None,
         "algorithmic_bytes_per_launch": alg_bytes,
-        "launches_per_step": 1,
-        "kernel_ms": mean[dom],
-        "timing": "HIP events on the launch stream, recorded inside libowl_mi355x.so around the kernel",
+        "launches_per_step": launches,
+        "kernel_ms": mean[dom] / launches,
+        "timing": "HIP events on the launch stream, recorded inside libowl_mi355x.so around the kernel's launches",
+        "groups": int(info.get("groups", 0)),
         "all_kernels_ms": {"core_flags": mean["core_ms"], "unions": mean["union_ms"], "labels": mean["label_ms"],
                            "whole_call": float(np.mean([i["solve_ms"] for i in infos]))},
         "point_distance_tests": {"core_flags": int(info["core_point_tests"]), "unions": int(info["union_point_tests"]),

@@ -189,14 +189,16 @@ typedef struct {
   int32_t clusters;
   float solve_ms;    /* HIP events around all launches of the call */
   float core_ms;     /* the three traversal kernels (events on the launch stream): core flags, */
-  float union_ms;    /* unions of core neighbours (the dominant kernel on dense sets),        */
+  float union_ms;    /* unions of neighbouring groups of core points: all launches of the union kernel, */
   float label_ms;    /* labels of border points (tknnDbscanAssign: its one traversal)         */
-  int32_t pad_;
+  int32_t union_launches; /* launches union_ms covers (2: groups that nearly touch, then the rest) */
   int64_t node_tests;         /* tree-node box tests over the three traversals */
   int64_t point_tests;        /* points whose distance to a query was computed (12 algorithmic bytes each) */
   int64_t core_point_tests;   /* ... per traversal */
   int64_t union_point_tests;
   int64_t label_point_tests;
+  int64_t union_node_tests;   /* node boxes (32 bytes each) the union kernel's walks looked at */
+  int64_t groups;             /* maximal tight nodes with a core point: the vertices of the union pass */
 } tknnDbscanInfo;
 TKNN_API int tknnDbscan(tknnEngine e, float eps, int min_pts, int32_t *d_labels, uint8_t *d_core,
                         int32_t *d_counts, tknnDbscanInfo *info, void *stream);

@@ -63,9 +63,10 @@ class SolveOptions(ctypes.Structure):
 
 class DbscanInfo(ctypes.Structure):
     _fields_ = [("clusters", ctypes.c_int32), ("solve_ms", ctypes.c_float), ("core_ms", ctypes.c_float),
-                ("union_ms", ctypes.c_float), ("label_ms", ctypes.c_float), ("pad_", ctypes.c_int32),
+                ("union_ms", ctypes.c_float), ("label_ms", ctypes.c_float), ("union_launches", ctypes.c_int32),
                 ("node_tests", ctypes.c_int64), ("point_tests", ctypes.c_int64), ("core_point_tests", ctypes.c_int64),
-                ("union_point_tests", ctypes.c_int64), ("label_point_tests", ctypes.c_int64)]
+                ("union_point_tests", ctypes.c_int64), ("label_point_tests", ctypes.c_int64),
+                ("union_node_tests", ctypes.c_int64), ("groups", ctypes.c_int64)]
 
     def as_dict(self):
         return {name: getattr(self, name) for name, _ in self._fields_ if name != "pad_"}

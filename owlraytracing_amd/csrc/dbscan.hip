@@ -53,6 +53,10 @@ struct DbArgs {
   // work counters, per traversal kernel k (0 core flags, 1 unions, 2 labels / assign): [2k] tree nodes
   // tested, [2k + 1] points whose distance to a query was computed (12 algorithmic bytes each)
   unsigned long long *stats;
+  int32_t *group_of;  // per sorted slot, written by the core-flag kernel (see db_group_kernel); null: not wanted
+  int chunk;  // packets per chunk dealt to an XCD (db_group_union_kernel)
+  float reach, near_lo2, near_hi2;  // this pass of db_group_union_kernel: groups whose nearest faces are near_lo2 < d^2 <= near_hi2 apart, reach >= sqrt(near_hi2)
+  int diag;  // TKNN_DB_DIAG (measurements only; results are wrong when set): 1 = no probes, 2 = no unions between groups, 4 = none inside groups
 };
 
 // a workgroup's counts into the kernel's two counters: wave sums, one LDS atomic per wave, one global
@@ -96,8 +100,9 @@ __device__ __forceinline__ int32_t uf_find(int32_t *parent, int32_t x) {
     int32_t p = uf_load(parent + x);
     if (p == x) return x;
     int32_t g = uf_load(parent + p);
-    if (g != p) __hip_atomic_store(parent + x, g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // path halving
-    x = p;
+    if (g == p) return p;  // p is a root
+    __hip_atomic_store(parent + x, g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // path halving
+    x = g;
   }
 }
 __device__ __forceinline__ void uf_unite(int32_t *parent, int32_t a, int32_t b) {
@@ -197,15 +202,17 @@ __device__ __forceinline__ void db_core_body(const DbArgs &a, int32_t t, uint32_
   const int32_t clean_end = bvh.n - (bvh.nan_count ? *bvh.nan_count : 0);  // NaN points sort last
   const float r = a.eps_wide;
   int32_t ref = bvh.root;
-  if (!a.want_counts) {
-    // the first tight node on my own root path: its points are pairwise within eps, so if it holds
-    // minPts of them I am core without looking any further
-    int32_t node = bvh.root;
+  if (!a.want_counts || a.group_of) {
+    // the first tight node on my own root path -- my GROUP (db_group_kernel): its points are pairwise within eps, so
+    // if it holds minPts of them I am core without looking any further
+    int32_t node = bvh.root, first = t;
     while (node >= 0) {
       const LbvhNode nd = bvh.nodes[node];
+      node_tests++;
       if (node_is_tight(nd, a.eps_in2)) {
-        const int32_t first = lbvh_first(node, nd.other), last = lbvh_last(node, nd.other);
-        if (last < clean_end && last - first + 1 >= a.min_pts) {
+        first = lbvh_first(node, nd.other);
+        const int32_t last = lbvh_last(node, nd.other);
+        if (!a.want_counts && last < clean_end && last - first + 1 >= a.min_pts) {
           cnt = last - first + 1;
           ref = LBVH_END;
         }
@@ -213,6 +220,8 @@ __device__ __forceinline__ void db_core_body(const DbArgs &a, int32_t t, uint32_
       }
       node = t <= nd.split ? lbvh_left_ref(node, nd) : lbvh_right_ref(node, nd);
     }
+    // the group's first slot keeps the group's reference (a node, or ~t for a point by itself), the others ~first
+    if (a.group_of) a.group_of[t] = t == first ? (node >= 0 ? node : ~t) : ~first;
   }
   while (ref != LBVH_END && cnt < stop_at) {
     if (ref >= 0) {
@@ -356,6 +365,254 @@ __global__ void __launch_bounds__(kDbBlock) db_union_kernel(DbArgs a) {
   db_add_stats(a.stats + 2, blk_stats, node_tests, point_tests);
 }
 
+// ---- unions by GROUP: one walk per maximal tight node ------------------------------------------------------------------
+// Every point lies in exactly one maximal tight node (a node whose box diagonal is below eps and whose parent's is not;
+// a leaf under a non-tight parent is one by itself): a GROUP.  A group's core points are one cluster, so the clusters are
+// the components of the graph of groups with an edge (A, B) iff some core point of A lies within eps of some core point
+// of B.  The per-point walk above pays a tree descent per POINT to the same ~100 neighbouring groups every other point of
+// its group reaches too (BASELINE config 3: 500 node tests per point, 40 of the call's 44 ms).  Here each group walks once,
+// box against tree, and only over the slots AFTER its own (the rope of its node is where a depth-first walk continues
+// behind it): a pair of groups is looked at exactly once, from its earlier end.
+//   group kernel: every point finds its group on its own root path; core points unite with the group's first core point;
+//                 the point at the group's first slot lists the group if it has a core point.
+//   union kernel: one lane per listed group.  A later group B in reach: no box point within eps (nearest faces) -> nothing;
+//                 same set already -> nothing; farthest corners within eps -> unite; otherwise PROBE: core points of A that
+//                 are within eps of B's box against B's core points, by the spec's distance arithmetic, until the first hit.
+__device__ __forceinline__ void box_box_dist2(const float *alo, const float *ahi, const float *blo, const float *bhi, float &far2,
+                                              float &near2) {
+  float f = 0.f, g = 0.f;
+#pragma unroll
+  for (int c = 0; c < 3; c++) {
+    const float fa = fmaxf(fabsf(ahi[c] - blo[c]), fabsf(bhi[c] - alo[c]));
+    const float ne = fmaxf(fmaxf(blo[c] - ahi[c], alo[c] - bhi[c]), 0.f);
+    f += fa * fa;
+    g += ne * ne;
+  }
+  far2 = f;
+  near2 = g;
+}
+
+struct DbIsGroup {
+  __host__ __device__ bool operator()(int32_t ref) const { return ref != LBVH_END; }
+};
+// per slot: the group's reference (node, or ~slot of a single point) at the group's first slot if the group has a core
+// point, LBVH_END everywhere else -- compacted into the list, in slot order, by a select.  The core-flag kernel has left
+// every point's group in group_of (it walks the point's root path anyway).
+__global__ void __launch_bounds__(kDbBlock) db_group_kernel(DbArgs a, int32_t *group_at) {
+  const LbvhView &bvh = a.bvh;
+  const int32_t t = blockIdx.x * kDbBlock + threadIdx.x;
+  if (t >= bvh.n) return;
+  const int32_t g = a.group_of[t];
+  const bool leads = g >= 0 || g == ~t;
+  const int32_t first = leads ? t : ~g;
+  const int32_t s = a.next_core[first];
+  if (a.core_sorted[t] && s != t && !(a.diag & 4)) uf_unite(a.parent, bvh.prim_id[t], bvh.prim_id[s]);  // s < t: both core, one group
+  int32_t out = LBVH_END;
+  if (leads) {
+    const int32_t last = g >= 0 ? lbvh_last(g, bvh.nodes[g].other) : t;
+    if (s <= last) out = g;
+  }
+  group_at[t] = out;
+}
+
+// Persistent waves, each working on one PACKET of 64 consecutive groups of the list at a time (Morton neighbours, more or
+// less: they meet the same nodes).  The wave walks the tree ONCE for the packet -- the walk is wave-uniform, one node or leaf
+// per step, tested against the 64 groups' boxes at once, lanes = groups -- and every lane collects, in its own LDS column,
+// the groups in ITS reach (nearest faces within eps) that lie after it; when a lane has kDbBuf waiting, the wave settles
+// what all lanes have collected: first core slots, rows and parent pointers fetched for all at once, then one after the
+// other.  (One walk per group, a lane each, was tried first: 320 node visits per group, each a 64-byte sector from HBM
+// because 8 000 waves at different places of a 320 MB tree share nothing in a 4 MB L2: 15 GB per launch, 5 ms.  The shared
+// walk visits a node once per packet.)
+constexpr int kDbBuf = 8;
+__global__ void __launch_bounds__(kDbBlock) db_group_union_kernel(DbArgs a, const int32_t *groups, const unsigned long long *n_groups,
+                                                                  unsigned long long *next_packet) {
+  __shared__ unsigned long long blk_stats[2];
+  __shared__ int32_t buf_ref[kDbBuf * kDbBlock];    // [entry][thread]: the group's node (or ~slot of a single point)
+  __shared__ int32_t buf_other[kDbBuf * kDbBlock];  // the other end of its slot range | far-corners-within-eps << 31
+  if (threadIdx.x < 2) blk_stats[threadIdx.x] = 0ull;
+  __syncthreads();
+  const LbvhView &bvh = a.bvh;
+  uint32_t node_tests = 0, point_tests = 0;
+  const long long total = (long long)*n_groups;
+  const long long packets = (total + 63) / 64;
+  const int lane = threadIdx.x & 63;
+  int32_t *my_ref = buf_ref + threadIdx.x, *my_other = buf_other + threadIdx.x;
+  const float r = a.reach;
+  const int xcc = (int)__builtin_amdgcn_s_getreg(6164 /* hwreg(HW_REG_XCC_ID, 0, 4) */) & 7;
+  const long long chunk = a.chunk;  // packets per chunk dealt to an XCD
+  uint32_t seg_empty = 0;           // XCDs whose chunks are used up (wave-uniform)
+  float alo[3], ahi[3];
+  int32_t a_last = 0, a_core = 0, mine = 0, my_root = 0;
+  // B = a tight node or a single leaf with box blo..bhi, first core slot b_core, last slot b_last: an edge?
+  auto probe = [&](const float *blo, const float *bhi, int32_t b_core, int32_t b_last) -> bool {
+    for (int32_t i = a_core; i <= a_last; i = a.next_core[i + 1]) {
+      const LbvhPoint p = bvh.points[i];
+      const float bx = fmaxf(fmaxf(blo[0] - p.x, p.x - bhi[0]), 0.f), by = fmaxf(fmaxf(blo[1] - p.y, p.y - bhi[1]), 0.f),
+                  bz = fmaxf(fmaxf(blo[2] - p.z, p.z - bhi[2]), 0.f);
+      if (bx * bx + by * by + bz * bz > a.eps_out2) continue;  // nothing of B within eps of p
+      for (int32_t j = b_core; j <= b_last; j = a.next_core[j + 1]) {
+        const LbvhPoint q = bvh.points[j];
+        point_tests++;
+        if (knn_sqrt(knn_dist2(q.x, q.y, q.z, p.x, p.y, p.z)) <= a.eps) return true;
+      }
+    }
+    return false;
+  };
+  int waiting = 0;
+  // what the lanes have collected: three rounds of loads for all of it, then one group after the other
+  auto settle = [&]() {
+    int32_t b_core[kDbBuf], b_last[kDbBuf], row[kDbBuf], par[kDbBuf];
+#pragma unroll
+    for (int w = 0; w < kDbBuf; w++) {
+      b_core[w] = 0x7fffffff;
+      b_last[w] = -1;
+      if (w < waiting) {
+        const int32_t x = my_ref[w * kDbBlock], o = my_other[w * kDbBlock] & 0x7fffffff;
+        const int32_t end = x >= 0 ? x : ~x;
+        b_last[w] = max(end, o);
+        b_core[w] = a.next_core[min(end, o)];
+      }
+    }
+#pragma unroll
+    for (int w = 0; w < kDbBuf; w++) {
+      row[w] = -1;
+      if (b_core[w] <= b_last[w]) row[w] = bvh.prim_id[b_core[w]];  // else: no core point in it (or no entry)
+    }
+#pragma unroll
+    for (int w = 0; w < kDbBuf; w++) {
+      par[w] = -1;
+      if (row[w] >= 0) par[w] = uf_load(a.parent + row[w]);
+    }
+#pragma unroll
+    for (int w = 0; w < kDbBuf; w++) {
+      if (row[w] < 0 || (a.diag & 2)) continue;
+      // a parent pointer never leaves its set: pointing at my root means "in my set" without walking to the root
+      if (par[w] == my_root) continue;
+      const int32_t other = row[w];
+      if (uf_find(a.parent, other) == my_root) continue;
+      my_root = uf_find(a.parent, my_root);  // my root may have been hooked under another meanwhile
+      if (uf_find(a.parent, other) == my_root) continue;
+      bool edge = my_other[w * kDbBlock] < 0;
+      if (!edge && !(a.diag & 1)) {
+        const int32_t B = my_ref[w * kDbBlock];
+        if (B >= 0) {
+          const LbvhNode nd = bvh.nodes[B];
+          edge = probe(nd.lo, nd.hi, b_core[w], b_last[w]);
+        } else {
+          const LbvhPoint q = bvh.points[~B];
+          const float b[3] = {q.x, q.y, q.z};
+          edge = probe(b, b, b_core[w], b_last[w]);
+        }
+      }
+      if (edge) {
+        uf_unite(a.parent, mine, other);
+        my_root = uf_find(a.parent, mine);
+      }
+    }
+    waiting = 0;
+  };
+  for (;;) {
+    // ---- take a packet.  Each XCD has its own L2: the list is dealt to the XCDs in chunks of packets, a wave takes from
+    // the chunks of the XCD it runs on and from the others' when those are used up.
+    long long packet = -1;
+    for (int t = 0; t < 8 && packet < 0; t++) {
+      const int from = (xcc + t) & 7;
+      if (seg_empty & (1u << from)) continue;
+      unsigned long long v = 0;
+      if (lane == 0) v = atomicAdd(next_packet + from, 1ull);
+      v = __shfl(v, 0);
+      const long long p = (((long long)v / chunk) * 8 + from) * chunk + (long long)v % chunk;
+      if (p < packets)
+        packet = p;
+      else
+        seg_empty |= 1u << from;  // places only grow: this XCD's chunks are used up
+    }
+    if (packet < 0) break;
+    // ---- lanes = the packet's groups
+    const long long g = packet * 64 + lane;
+    const bool have = g < total;
+    int32_t a_first = 0x7fffffff;
+    a_last = 0x7fffffff;  // a lane without a group: nothing lies after it
+    alo[0] = alo[1] = alo[2] = ahi[0] = ahi[1] = ahi[2] = 0.f;
+    if (have) {
+      const int32_t G = groups[g];
+      if (G >= 0) {
+        const LbvhNode nd = bvh.nodes[G];
+        for (int c = 0; c < 3; c++) alo[c] = nd.lo[c], ahi[c] = nd.hi[c];
+        a_first = lbvh_first(G, nd.other);
+        a_last = lbvh_last(G, nd.other);
+      } else {
+        const LbvhPoint p = bvh.points[~G];
+        alo[0] = ahi[0] = p.x, alo[1] = ahi[1] = p.y, alo[2] = ahi[2] = p.z;
+        a_first = a_last = ~G;
+      }
+      a_core = a.next_core[a_first];  // <= a_last: listed groups have a core point
+      mine = bvh.prim_id[a_core];
+      my_root = uf_find(a.parent, mine);
+    }
+    // nothing before the packet's earliest group end can lie after any of its groups
+    int32_t low = a_last;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) low = min(low, __shfl_xor(low, off));
+    // ---- the packet's walk (wave-uniform)
+    int32_t ref = bvh.root;
+    while (ref != LBVH_END) {
+      ref = __builtin_amdgcn_readfirstlane(ref);
+      const bool is_node = ref >= 0;
+      const int32_t slot = is_node ? 0 : ~ref;
+      float blo[3], bhi[3];
+      int32_t rope, b_first, b_last, b_other, split = 0;
+      bool tight, any_core = true;
+      if (is_node) {
+        const LbvhNode nd = bvh.nodes[ref];
+        rope = bvh.rope_node[ref];
+        for (int c = 0; c < 3; c++) blo[c] = nd.lo[c], bhi[c] = nd.hi[c];
+        b_other = nd.other;
+        split = nd.split;
+        b_first = lbvh_first(ref, nd.other);
+        b_last = lbvh_last(ref, nd.other);
+        tight = node_is_tight(nd, a.eps_in2);
+      } else {
+        const LbvhPoint q = bvh.points[slot];
+        rope = bvh.rope_leaf[slot];
+        any_core = a.core_sorted[slot] != 0;
+        blo[0] = bhi[0] = q.x, blo[1] = bhi[1] = q.y, blo[2] = bhi[2] = q.z;
+        b_other = b_first = b_last = slot;
+        tight = true;
+      }
+      if (lane == 0) node_tests++;
+      int32_t next = rope;
+      if (b_last > low && any_core) {
+        const bool hit = (blo[0] - r <= ahi[0]) & (alo[0] <= bhi[0] + r) & (blo[1] - r <= ahi[1]) & (alo[1] <= bhi[1] + r) &
+                         (blo[2] - r <= ahi[2]) & (alo[2] <= bhi[2] + r) & (b_last > a_last);
+        if (__ballot(hit) != 0ull) {
+          if (tight) {  // the walk only descends through nodes that are not tight: this one is maximal, a group
+            float far2, near2;
+            box_box_dist2(alo, ahi, blo, bhi, far2, near2);
+            if (hit && b_first > a_last && near2 <= a.near_hi2 && near2 > a.near_lo2) {
+              my_ref[waiting * kDbBlock] = ref;
+              my_other[waiting * kDbBlock] = b_other | (far2 <= a.eps_in2 ? (int32_t)0x80000000 : 0);
+              waiting++;
+            }
+            if (__ballot(waiting == kDbBuf) != 0ull) settle();
+          } else {
+            next = b_first == split ? ~split : split;  // lbvh_left_ref
+          }
+        }
+      }
+      ref = next;
+    }
+    if (__ballot(waiting > 0) != 0ull) settle();
+  }
+  if (a.diag & 8) {  // [6] most walk steps of a wave, [7] their sum
+    if (lane == 0) {
+      atomicMax(&a.stats[6], (unsigned long long)node_tests);
+      atomicAdd(&a.stats[7], (unsigned long long)node_tests);
+    }
+  }
+  db_add_stats(a.stats + 2, blk_stats, node_tests, point_tests);
+}
+
 // after the unions: point every core at its root and flag roots for the ranking scan
 __global__ void __launch_bounds__(kDbBlock) db_flatten_kernel(DbArgs a, int32_t *is_root) {
   const int32_t t = blockIdx.x * kDbBlock + threadIdx.x;
@@ -494,8 +751,10 @@ void Engine::dbscan(float eps, int min_pts, int32_t *d_labels, uint8_t *d_core, 
   const int64_t n = bvh_.size();
   // scratch: core flags per slot, parent, root flags, ranks
   const size_t need = (((size_t)n * (1 + 4 + 4 + 4 + 4)) + 16 + 255) / 256 * 256;  // + next_core, + two sentinels
-  size_t scan_bytes = 0;
+  size_t scan_bytes = 0, select_bytes = 0;
   OWLMI_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, (int32_t *)nullptr, (int32_t *)nullptr, (int)n, s));
+  OWLMI_HIP(hipcub::DeviceSelect::If(nullptr, select_bytes, (int32_t *)nullptr, (int32_t *)nullptr, (unsigned long long *)nullptr, (int)n, DbIsGroup(), s));
+  scan_bytes = std::max(scan_bytes, select_bytes);
   if (need + scan_bytes > wave_ws_bytes_) {
     if (wave_ws_) (void)hipFree(wave_ws_);
     wave_ws_ = nullptr;
@@ -510,6 +769,7 @@ void Engine::dbscan(float eps, int min_pts, int32_t *d_labels, uint8_t *d_core, 
   a.min_pts = min_pts;
   a.want_counts = d_counts != nullptr;
   a.keep_core = 0;
+  a.diag = getenv("TKNN_DB_DIAG") ? atoi(getenv("TKNN_DB_DIAG")) : 0;
   a.parent = (int32_t *)ws;
   int32_t *is_root = (int32_t *)(ws + (size_t)n * 4);
   a.rank = (int32_t *)(ws + (size_t)n * 8);  // n + 1 entries
@@ -522,9 +782,13 @@ void Engine::dbscan(float eps, int min_pts, int32_t *d_labels, uint8_t *d_core, 
   a.core = d_core;
   a.counts = d_counts;
   a.labels = d_labels;
+  const char *union_env = getenv("TKNN_DBSCAN_UNION");  // "point": the per-point union walk (A/B measurements, tests); read per call
+  const bool per_point = union_env && std::strcmp(union_env, "point") == 0;
+  // every point's group, for the union pass; kept in the caller's label array, which is written last
+  a.group_of = core_label || per_point ? nullptr : d_labels;
   const unsigned blocks = (unsigned)((n + kDbBlock - 1) / kDbBlock);
   a.stats = counters_;  // [0..5]: node / point tests of the three traversal kernels
-  OWLMI_HIP(hipMemsetAsync(counters_, 0, 6 * sizeof(unsigned long long), s));
+  OWLMI_HIP(hipMemsetAsync(counters_, 0, 8 * sizeof(unsigned long long), s));
   hipEvent_t e0 = ev_a_, e1 = ev_b_;
   OWLMI_HIP(hipEventRecord(e0, s));
   if (core_label) {
@@ -564,8 +828,48 @@ void Engine::dbscan(float eps, int min_pts, int32_t *d_labels, uint8_t *d_core, 
     }
     return;
   }
-  OWLMI_HIP(hipEventRecord(ev_d_, s));
-  hipLaunchKernelGGL(db_union_kernel, dim3(blocks), dim3(kDbBlock), 0, s, a);
+  int union_launches = 1;
+  if (per_point) {
+    OWLMI_HIP(hipEventRecord(ev_d_, s));
+    hipLaunchKernelGGL(db_union_kernel, dim3(blocks), dim3(kDbBlock), 0, s, a);
+  } else {
+    // per-slot group references where the ranks go afterwards, the list itself (slot order = Morton order: neighbours in
+    // the list are neighbours in space) where the root flags go; its length in counters_[8], the XCDs' cursors in [9..16]
+    int32_t *group_at = a.rank, *groups = is_root;
+    unsigned long long *n_groups = counters_ + 8;
+    OWLMI_HIP(hipMemsetAsync(n_groups, 0, 9 * sizeof(unsigned long long), s));
+    a.chunk = getenv("TKNN_DB_CHUNK") ? std::max(1, atoi(getenv("TKNN_DB_CHUNK"))) : 64;
+    hipLaunchKernelGGL(db_group_kernel, dim3(blocks), dim3(kDbBlock), 0, s, a, group_at);
+    OWLMI_HIP(hipcub::DeviceSelect::If(scan_tmp, scan_bytes, group_at, groups, n_groups, (int)n, DbIsGroup(), s));
+    // persistent lanes: as many workgroups as the device holds at once (the list's length is known on the device only)
+    static const int resident = [] {
+      int per_cu = 0, dev = 0;
+      hipDeviceProp_t prop;
+      if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 256 * 4;
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)db_group_union_kernel, kDbBlock, 0) != hipSuccess) per_cu = 4;
+      return prop.multiProcessorCount * std::max(1, per_cu);
+    }();
+    unsigned grid = blocks < (unsigned)resident ? blocks : (unsigned)resident;
+    if (getenv("TKNN_DB_GRID")) grid = std::max(1, std::min((int)grid, atoi(getenv("TKNN_DB_GRID"))));  // measurements
+    // Two passes: first the pairs of groups that (nearly) touch -- in a dense region their probes hit at once, and when the
+    // pass is over a cluster's groups are one set --, then the pairs further apart, nearly all of which then are in one
+    // set already and cost a parent read instead of a probe that would have to look at many point pairs to find one close
+    // enough (or none).  One pass settles everything as soon as it is met: 4 times the point tests, 14 ms instead of 4.
+    const float split = getenv("TKNN_DB_SPLIT") ? (float)atof(getenv("TKNN_DB_SPLIT")) : 0.25f;
+    a.near_lo2 = -1.f;
+    a.near_hi2 = split * split * a.eps_out2;
+    a.reach = split * a.eps_wide;
+    OWLMI_HIP(hipEventRecord(ev_d_, s));
+    if (split < 1.f) {
+      union_launches = 2;
+      hipLaunchKernelGGL(db_group_union_kernel, dim3(grid), dim3(kDbBlock), 0, s, a, groups, n_groups, n_groups + 1);
+      OWLMI_HIP(hipMemsetAsync(n_groups + 1, 0, 8 * sizeof(unsigned long long), s));
+      a.near_lo2 = a.near_hi2;
+    }
+    a.near_hi2 = a.eps_out2;
+    a.reach = a.eps_wide;
+    hipLaunchKernelGGL(db_group_union_kernel, dim3(grid), dim3(kDbBlock), 0, s, a, groups, n_groups, n_groups + 1);
+  }
   OWLMI_HIP(hipEventRecord(ev_e_, s));
   hipLaunchKernelGGL(db_flatten_kernel, dim3(blocks), dim3(kDbBlock), 0, s, a, is_root);
   OWLMI_HIP(hipGetLastError());
@@ -574,7 +878,7 @@ void Engine::dbscan(float eps, int min_pts, int32_t *d_labels, uint8_t *d_core, 
   hipLaunchKernelGGL(db_label_kernel, dim3(blocks), dim3(kDbBlock), 0, s, a);
   OWLMI_HIP(hipGetLastError());
   OWLMI_HIP(hipEventRecord(e1, s));
-  OWLMI_HIP(hipMemcpyAsync(h_counters_, counters_, 6 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+  OWLMI_HIP(hipMemcpyAsync(h_counters_, counters_, 9 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
   // number of clusters = rank[n-1] + is_root[n-1]
   int32_t last[2] = {0, 0};
   OWLMI_HIP(hipMemcpyAsync(&last[0], a.rank + (n - 1), 4, hipMemcpyDeviceToHost, s));
@@ -594,6 +898,12 @@ void Engine::dbscan(float eps, int min_pts, int32_t *d_labels, uint8_t *d_core, 
     info->core_point_tests = (int64_t)h_counters_[1];
     info->union_point_tests = (int64_t)h_counters_[3];
     info->label_point_tests = (int64_t)h_counters_[5];
+    info->union_launches = union_launches;
+    info->union_node_tests = (int64_t)h_counters_[2];
+    info->groups = per_point ? 0 : (int64_t)h_counters_[8];
+    if (a.diag & 8)
+      std::fprintf(stderr, "[dbscan] groups %llu  union-phase node tests %llu  longest walk %llu  mean of the waves' longest %.0f\n", h_counters_[8],
+                   h_counters_[2], h_counters_[6], (double)h_counters_[7] / ((double)((h_counters_[8] + 63) / 64) + 1e-9));
   }
 }
 

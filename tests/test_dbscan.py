@@ -102,6 +102,43 @@ def test_hip_dbscan_larger_mixture_against_the_spec_and_sklearn():
 
 
 @pytest.mark.gpu
+def test_group_unions_equal_point_unions(monkeypatch):
+    """The union pass walks once per GROUP (maximal tight node); TKNN_DBSCAN_UNION=point selects the per-point walk it
+    replaced.  Both must give the spec's labels -- also where groups face each other across a gap close to eps (probes that
+    find nothing), on a lattice whose spacing is eps itself, and with exact duplicates."""
+    from owlraytracing_amd.trueknn import TrueKNN
+    rng = np.random.default_rng(11)
+    slab = lambda m: rng.uniform(0, 1, (m, 3)).astype(np.float32) * np.float32([0.2, 0.2, 0.02])
+    g = np.arange(24, dtype=np.float32) * np.float32(0.01)
+    lattice = np.stack(np.meshgrid(g, g, g, indexing="ij"), -1).reshape(-1, 3).astype(np.float32) + np.float32(0.37)
+    dup = datasets.uniform3d(20000, seed=12)
+    dup[rng.choice(20000, 8000, replace=False)] = dup[rng.integers(0, 20000, 8000)]
+    cases = [
+        ("gmm", datasets.gaussian_mixture3d(150_000, components=16, sigma=0.02, seed=2), 0.01, 4),
+        ("slabs_apart", np.concatenate([slab(40000), slab(40000) + np.float32([0, 0, 0.0301])]), 0.0099, 4),
+        ("slabs_joined", np.concatenate([slab(40000), slab(40000) + np.float32([0, 0, 0.0301])]), 0.0104, 4),
+        ("lattice_at_eps", lattice, float(np.float32(0.01)), 3),
+        ("lattice_below_eps", lattice, float(np.float32(0.01 * (1 - 1e-6))), 3),
+        ("duplicates", dup, 0.02, 3),
+    ]
+    eng = TrueKNN()
+    for name, xyz, eps, min_pts in cases:
+        eps = float(np.float32(eps))
+        ref = oracle.dbscan(xyz, eps, min_pts)
+        eng.build(xyz)
+        monkeypatch.delenv("TKNN_DBSCAN_UNION", raising=False)
+        by_group = eng.dbscan(eps, min_pts)
+        monkeypatch.setenv("TKNN_DBSCAN_UNION", "point")
+        by_point = eng.dbscan(eps, min_pts)
+        monkeypatch.delenv("TKNN_DBSCAN_UNION", raising=False)
+        assert np.array_equal(by_group["labels"].cpu().numpy(), ref["labels"]), name
+        assert np.array_equal(by_point["labels"].cpu().numpy(), ref["labels"]), name
+        assert by_group["info"]["clusters"] == ref["clusters"] == by_point["info"]["clusters"], name
+        assert by_group["info"]["node_tests"] < by_point["info"]["node_tests"], name
+    eng.close()
+
+
+@pytest.mark.gpu
 def test_hip_dbscan_argument_errors():
     from owlraytracing_amd import _lib
     from owlraytracing_amd.trueknn import TrueKNN
