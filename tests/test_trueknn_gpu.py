@@ -230,6 +230,24 @@ def test_tie_heavy_sets_equal_the_replay(kernel, tail, k, monkeypatch):
         eng.close()
 
 
+def test_wave_kernel_redo_path_with_more_tie_rows_than_the_list_holds(monkeypatch):
+    """The wave kernel re-solves its queries when its LDS stack overflows; TKNN_WAVE_FORCE_REDO takes that path without a
+    pathological tree.  On a lattice nearly every row is flagged for the tie pass: more than the 4096 the device-side
+    list holds, so the pass must take its row count from the flags, not from the list (the list's length had
+    been read as the number of rows)."""
+    xyz = _lattice(28, 3, 5)  # ~17 500 points, every one with ties
+    k, r0 = 8, 0.02
+    ref = oracle.trueknn(xyz, k, r0)
+    monkeypatch.setenv("TKNN_WAVE_FORCE_REDO", "1")  # read when the engine is created
+    eng = _engine()
+    eng.build(xyz)
+    r = eng.solve(k, r0, kernel=_lib.KERNEL_WAVE)
+    assert r["info"]["tie_rows"] > 4096 and r["info"]["tie_rows_left"] == 0
+    assert np.array_equal(r["intersections"].cpu().numpy(), ref["intersections"])
+    assert_rows_equal(r["idx"].cpu().numpy(), r["dist"].cpu().numpy(), ref["idx"], ref["dist"])
+    eng.close()
+
+
 def test_candidate_thresholds_equal_the_literal_box_test():
     """lo <= c <= hi must select exactly the c with fl(c - r) <= q <= fl(c + r), including near
     zero, across binades and at exact box boundaries (where a per-ulp walk would take forever)."""
