@@ -415,20 +415,45 @@ __global__ void __launch_bounds__(kDbBlock) db_group_kernel(DbArgs a, int32_t *g
   group_at[t] = out;
 }
 
-// Persistent waves, each working on one PACKET of 64 consecutive groups of the list at a time (Morton neighbours, more or
-// less: they meet the same nodes).  The wave walks the tree ONCE for the packet -- the walk is wave-uniform, one node or leaf
-// per step, tested against the 64 groups' boxes at once, lanes = groups -- and every lane collects, in its own LDS column,
-// the groups in ITS reach (nearest faces within eps) that lie after it; when a lane has kDbBuf waiting, the wave settles
-// what all lanes have collected: first core slots, rows and parent pointers fetched for all at once, then one after the
-// other.  (One walk per group, a lane each, was tried first: 320 node visits per group, each a 64-byte sector from HBM
-// because 8 000 waves at different places of a 320 MB tree share nothing in a 4 MB L2: 15 GB per launch, 5 ms.  The shared
-// walk visits a node once per packet.)
+// Persistent waves, each working on one PACKET of 64 consecutive groups of the list at a time (Morton neighbours: they
+// meet the same nodes).  The wave walks the tree ONCE for the packet, in two alternating roles:
+//   lanes = nodes: up to 64 references are popped from the wave's LDS stack and their boxes (a leaf's is its point)
+//                  loaded at once and put into LDS;
+//   lanes = groups: every popped box, read from LDS by all lanes, is tested against each lane's own group widened by the
+//                  reach.  A node no group reaches is dropped.  A tight node (the walk only descends through nodes that are
+//                  not: it is maximal, a group) or a core leaf is collected, in the lane's own LDS column, by every group
+//                  that has it in reach (nearest faces within eps) and lies before it; when a lane has kDbBuf waiting, the
+//                  wave settles what all lanes have collected: first core slots, rows and parent pointers fetched for all
+//                  at once, then one after the other.
+//   lanes = nodes: the nodes some group reaches that are not tight push their children.
+// (History, BASELINE config 3, union pass: a walk per POINT 40 ms; a walk per group, one lane each, 5 ms -- 320 node visits
+// per group, each a 64-byte sector from memory because 8 000 waves at different places of a 320 MB tree share nothing in a
+// 4 MB L2: 15 GB per launch; one rope walk per packet, wave-uniform, 1.8 ms per launch -- 1 300 dependent loads in a row;
+// the stack walk needs some 40 rounds of loads per packet; with the popped nodes tested against the packet's bounding box
+// instead of its 64 groups, a packet across a jump of the Z-curve walked half the tree: one wave, 4 ms.)
 constexpr int kDbBuf = 8;
+constexpr int kDbStack = 1024;  // references per wave; popped one at a time (depth first) when fewer than 256 places are left
+constexpr int kDbCand = 64;     // the boxes popped in one round, per wave
+struct DbCand {
+  float lo[3];
+  int32_t ref;    // node, or ~slot of a single point
+  float hi[3];
+  int32_t other;  // the other end of the node's slot range (a leaf: its slot)
+};
+__device__ __forceinline__ void db_wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 __global__ void __launch_bounds__(kDbBlock) db_group_union_kernel(DbArgs a, const int32_t *groups, const unsigned long long *n_groups,
-                                                                  unsigned long long *next_packet) {
+                                                                  unsigned long long *next_packet, unsigned long long *overflow) {
   __shared__ unsigned long long blk_stats[2];
   __shared__ int32_t buf_ref[kDbBuf * kDbBlock];    // [entry][thread]: the group's node (or ~slot of a single point)
   __shared__ int32_t buf_other[kDbBuf * kDbBlock];  // the other end of its slot range | far-corners-within-eps << 31
+  __shared__ int32_t stack_all[(kDbBlock / 64) * kDbStack];
+  __shared__ __align__(16) DbCand cand_all[(kDbBlock / 64) * kDbCand];
+  int32_t *stack = stack_all + (threadIdx.x >> 6) * kDbStack;
+  DbCand *cand = cand_all + (threadIdx.x >> 6) * kDbCand;
   if (threadIdx.x < 2) blk_stats[threadIdx.x] = 0ull;
   __syncthreads();
   const LbvhView &bvh = a.bvh;
@@ -438,6 +463,7 @@ __global__ void __launch_bounds__(kDbBlock) db_group_union_kernel(DbArgs a, cons
   const int lane = threadIdx.x & 63;
   int32_t *my_ref = buf_ref + threadIdx.x, *my_other = buf_other + threadIdx.x;
   const float r = a.reach;
+  typedef float t_f4 __attribute__((ext_vector_type(4)));
   const int xcc = (int)__builtin_amdgcn_s_getreg(6164 /* hwreg(HW_REG_XCC_ID, 0, 4) */) & 7;
   const long long chunk = a.chunk;  // packets per chunk dealt to an XCD
   uint32_t seg_empty = 0;           // XCDs whose chunks are used up (wave-uniform)
@@ -554,53 +580,77 @@ __global__ void __launch_bounds__(kDbBlock) db_group_union_kernel(DbArgs a, cons
     int32_t low = a_last;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) low = min(low, __shfl_xor(low, off));
-    // ---- the packet's walk (wave-uniform)
-    int32_t ref = bvh.root;
-    while (ref != LBVH_END) {
-      ref = __builtin_amdgcn_readfirstlane(ref);
+    // ---- the packet's walk
+    const unsigned long long below = (1ull << lane) - 1ull;
+    int top = 1;
+    if (lane == 0) stack[0] = bvh.root;
+    db_wave_sync();
+    while (top > 0) {
+      // lanes = nodes: pop, load, stage
+      const int width = top > kDbStack - 256 ? 1 : 64;
+      const int n_pop = min(top, width);
+      const bool valid = lane < n_pop;
+      const int32_t ref = valid ? stack[top - 1 - lane] : bvh.root;
+      top -= n_pop;
       const bool is_node = ref >= 0;
       const int32_t slot = is_node ? 0 : ~ref;
-      float blo[3], bhi[3];
-      int32_t rope, b_first, b_last, b_other, split = 0;
-      bool tight, any_core = true;
-      if (is_node) {
-        const LbvhNode nd = bvh.nodes[ref];
-        rope = bvh.rope_node[ref];
-        for (int c = 0; c < 3; c++) blo[c] = nd.lo[c], bhi[c] = nd.hi[c];
-        b_other = nd.other;
-        split = nd.split;
-        b_first = lbvh_first(ref, nd.other);
-        b_last = lbvh_last(ref, nd.other);
-        tight = node_is_tight(nd, a.eps_in2);
-      } else {
-        const LbvhPoint q = bvh.points[slot];
-        rope = bvh.rope_leaf[slot];
-        any_core = a.core_sorted[slot] != 0;
-        blo[0] = bhi[0] = q.x, blo[1] = bhi[1] = q.y, blo[2] = bhi[2] = q.z;
-        b_other = b_first = b_last = slot;
-        tight = true;
+      const t_f4 *src = is_node ? (const t_f4 *)(bvh.nodes + ref) : (const t_f4 *)(bvh.points + slot);
+      const t_f4 v0 = src[0], v1 = src[is_node ? 1 : 0];
+      const bool any_core = is_node || a.core_sorted[slot] != 0;
+      if (valid) node_tests++;
+      const int32_t split = __float_as_int(v0.w), b_other = is_node ? __float_as_int(v1.w) : slot;
+      const int32_t my_end = is_node ? ref : slot;
+      const int32_t b_first = min(my_end, b_other), b_last = max(my_end, b_other);
+      const float ex = v1.x - v0.x, ey = v1.y - v0.y, ez = v1.z - v0.z;
+      const bool tight = !is_node || ex * ex + ey * ey + ez * ez <= a.eps_in2;  // node_is_tight
+      {
+        DbCand &e = cand[lane];
+        e.lo[0] = v0.x, e.lo[1] = v0.y, e.lo[2] = v0.z;
+        e.ref = ref;
+        e.hi[0] = v1.x, e.hi[1] = v1.y, e.hi[2] = v1.z;
+        e.other = b_other;
       }
-      if (lane == 0) node_tests++;
-      int32_t next = rope;
-      if (b_last > low && any_core) {
-        const bool hit = (blo[0] - r <= ahi[0]) & (alo[0] <= bhi[0] + r) & (blo[1] - r <= ahi[1]) & (alo[1] <= bhi[1] + r) &
-                         (blo[2] - r <= ahi[2]) & (alo[2] <= bhi[2] + r) & (b_last > a_last);
-        if (__ballot(hit) != 0ull) {
-          if (tight) {  // the walk only descends through nodes that are not tight: this one is maximal, a group
-            float far2, near2;
-            box_box_dist2(alo, ahi, blo, bhi, far2, near2);
-            if (hit && b_first > a_last && near2 <= a.near_hi2 && near2 > a.near_lo2) {
-              my_ref[waiting * kDbBlock] = ref;
-              my_other[waiting * kDbBlock] = b_other | (far2 <= a.eps_in2 ? (int32_t)0x80000000 : 0);
-              waiting++;
-            }
-            if (__ballot(waiting == kDbBuf) != 0ull) settle();
-          } else {
-            next = b_first == split ? ~split : split;  // lbvh_left_ref
-          }
+      // nodes nothing can come of: past the packet's last use, or a leaf that is not core
+      const unsigned long long m_live = __ballot(valid && any_core && b_last > low), m_tight = __ballot(tight);
+      db_wave_sync();
+      // lanes = groups
+      unsigned long long m_open = 0ull;  // nodes some group reaches and that are not tight
+      for (unsigned long long todo = m_live; todo;) {
+        const int j = __ffsll((long long)todo) - 1;
+        todo &= todo - 1ull;
+        const DbCand e = cand[j];
+        const int32_t e_end = e.ref >= 0 ? e.ref : ~e.ref;
+        const int32_t e_first = min(e_end, e.other), e_last = max(e_end, e.other);
+        const bool hit = (e.lo[0] - r <= ahi[0]) & (alo[0] <= e.hi[0] + r) & (e.lo[1] - r <= ahi[1]) & (alo[1] <= e.hi[1] + r) &
+                         (e.lo[2] - r <= ahi[2]) & (alo[2] <= e.hi[2] + r) & (e_last > a_last);
+        if (__ballot(hit) == 0ull) continue;
+        if (!((m_tight >> j) & 1ull)) {
+          m_open |= 1ull << j;
+          continue;
         }
+        float far2, near2;
+        box_box_dist2(alo, ahi, e.lo, e.hi, far2, near2);
+        if (hit && e_first > a_last && near2 <= a.near_hi2 && near2 > a.near_lo2) {
+          my_ref[waiting * kDbBlock] = e.ref;
+          my_other[waiting * kDbBlock] = e.other | (far2 <= a.eps_in2 ? (int32_t)0x80000000 : 0);
+          waiting++;
+        }
+        if (__ballot(waiting == kDbBuf) != 0ull) settle();
       }
-      ref = next;
+      // lanes = nodes: children (the left one only if it reaches past the packet's earliest group)
+      const bool kids = (m_open >> lane) & 1ull;
+      const bool left_too = kids && split > low;
+      const unsigned long long m_left = __ballot(left_too);
+      const int n_left = __popcll(m_left), n_right = __popcll(m_open);
+      if (top + n_left + n_right > kDbStack) {  // (cannot happen below a tree depth of some 250 levels; the host then falls back)
+        if (lane == 0) atomicAdd(overflow, 1ull);
+        top = 0;
+        break;
+      }
+      if (left_too) stack[top + __popcll(m_left & below)] = b_first == split ? ~split : split;                              // lbvh_left_ref
+      if (kids) stack[top + n_left + __popcll(m_open & below)] = b_last == split + 1 ? ~(split + 1) : split + 1;  // lbvh_right_ref
+      top += n_left + n_right;
+      db_wave_sync();
     }
     if (__ballot(waiting > 0) != 0ull) settle();
   }
@@ -783,7 +833,7 @@ void Engine::dbscan(float eps, int min_pts, int32_t *d_labels, uint8_t *d_core, 
   a.counts = d_counts;
   a.labels = d_labels;
   const char *union_env = getenv("TKNN_DBSCAN_UNION");  // "point": the per-point union walk (A/B measurements, tests); read per call
-  const bool per_point = union_env && std::strcmp(union_env, "point") == 0;
+  const bool per_point = db_force_point_ || (union_env && std::strcmp(union_env, "point") == 0);
   // every point's group, for the union pass; kept in the caller's label array, which is written last
   a.group_of = core_label || per_point ? nullptr : d_labels;
   const unsigned blocks = (unsigned)((n + kDbBlock - 1) / kDbBlock);
@@ -837,7 +887,7 @@ void Engine::dbscan(float eps, int min_pts, int32_t *d_labels, uint8_t *d_core, 
     // the list are neighbours in space) where the root flags go; its length in counters_[8], the XCDs' cursors in [9..16]
     int32_t *group_at = a.rank, *groups = is_root;
     unsigned long long *n_groups = counters_ + 8;
-    OWLMI_HIP(hipMemsetAsync(n_groups, 0, 9 * sizeof(unsigned long long), s));
+    OWLMI_HIP(hipMemsetAsync(n_groups, 0, 10 * sizeof(unsigned long long), s));  // ... and the count of stack overflows in [17]
     a.chunk = getenv("TKNN_DB_CHUNK") ? std::max(1, atoi(getenv("TKNN_DB_CHUNK"))) : 64;
     hipLaunchKernelGGL(db_group_kernel, dim3(blocks), dim3(kDbBlock), 0, s, a, group_at);
     OWLMI_HIP(hipcub::DeviceSelect::If(scan_tmp, scan_bytes, group_at, groups, n_groups, (int)n, DbIsGroup(), s));
@@ -862,13 +912,13 @@ void Engine::dbscan(float eps, int min_pts, int32_t *d_labels, uint8_t *d_core, 
     OWLMI_HIP(hipEventRecord(ev_d_, s));
     if (split < 1.f) {
       union_launches = 2;
-      hipLaunchKernelGGL(db_group_union_kernel, dim3(grid), dim3(kDbBlock), 0, s, a, groups, n_groups, n_groups + 1);
+      hipLaunchKernelGGL(db_group_union_kernel, dim3(grid), dim3(kDbBlock), 0, s, a, groups, n_groups, n_groups + 1, n_groups + 9);
       OWLMI_HIP(hipMemsetAsync(n_groups + 1, 0, 8 * sizeof(unsigned long long), s));
       a.near_lo2 = a.near_hi2;
     }
     a.near_hi2 = a.eps_out2;
     a.reach = a.eps_wide;
-    hipLaunchKernelGGL(db_group_union_kernel, dim3(grid), dim3(kDbBlock), 0, s, a, groups, n_groups, n_groups + 1);
+    hipLaunchKernelGGL(db_group_union_kernel, dim3(grid), dim3(kDbBlock), 0, s, a, groups, n_groups, n_groups + 1, n_groups + 9);
   }
   OWLMI_HIP(hipEventRecord(ev_e_, s));
   hipLaunchKernelGGL(db_flatten_kernel, dim3(blocks), dim3(kDbBlock), 0, s, a, is_root);
@@ -879,11 +929,24 @@ void Engine::dbscan(float eps, int min_pts, int32_t *d_labels, uint8_t *d_core, 
   OWLMI_HIP(hipGetLastError());
   OWLMI_HIP(hipEventRecord(e1, s));
   OWLMI_HIP(hipMemcpyAsync(h_counters_, counters_, 9 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+  OWLMI_HIP(hipMemcpyAsync(h_counters_ + 9, counters_ + 17, sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
   // number of clusters = rank[n-1] + is_root[n-1]
   int32_t last[2] = {0, 0};
   OWLMI_HIP(hipMemcpyAsync(&last[0], a.rank + (n - 1), 4, hipMemcpyDeviceToHost, s));
   OWLMI_HIP(hipMemcpyAsync(&last[1], is_root + (n - 1), 4, hipMemcpyDeviceToHost, s));
   OWLMI_HIP(hipStreamSynchronize(s));
+  if (!per_point && h_counters_[9] != 0 && !db_force_point_) {
+    // a packet's walk ran out of stack (a tree some 250 levels deep): the whole call again with the per-point unions
+    db_force_point_ = true;
+    try {
+      dbscan(eps, min_pts, d_labels, d_core, d_counts, info, s, core_label);
+    } catch (...) {
+      db_force_point_ = false;
+      throw;
+    }
+    db_force_point_ = false;
+    return;
+  }
   if (info) {
     float ms = 0;
     std::memset(info, 0, sizeof *info);

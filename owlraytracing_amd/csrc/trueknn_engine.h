@@ -102,6 +102,7 @@ class Engine {
   unsigned long long *counters_ = nullptr, *h_counters_ = nullptr;
   void *wave_ws_ = nullptr;
   size_t wave_ws_bytes_ = 0;
+  bool db_force_point_ = false;   // dbscan(): per-point unions (the fallback when a packet walk of the group unions ran out of stack)
   bool wave_force_redo_ = false;  // TKNN_WAVE_FORCE_REDO (tests): treat every wave-kernel solve as if its LDS stack had overflowed
   int wave_leaf_max_ = 16;  // subtrees of at most this many points are streamed as one range (TKNN_LEAF_MAX)
   int32_t *slot_list_ = nullptr;  // compact list of the sorted slots the team kernel handed over (+ its length)
