@@ -45,8 +45,9 @@ struct DbArgs {
   uint8_t *core_sorted;  // per sorted slot
   uint8_t *core;         // per caller index (may be null)
   int32_t *counts;       // per caller index (may be null)
-  int32_t *parent;       // per caller index
-  int32_t *rank;         // per caller index: cluster label of a root
+  int32_t *parent;       // union-find over SORTED SLOTS (the smaller slot stays root): neighbours in space are neighbours in memory
+  int32_t *min_row;      // per slot, meaningful at roots: the smallest row (caller index) among the cluster's core points
+  int32_t *rank;         // per caller index: cluster label of the cluster whose smallest core row it is
   int32_t *labels;       // per caller index
   const int32_t *next_core;  // per sorted slot (+1 sentinel): first core slot at or after it, n if none
   float eps_in2, eps_out2;   // eps^2 (1 -+ 1e-5): below / above these, fp32 distance arithmetic cannot disagree
@@ -117,10 +118,10 @@ __device__ __forceinline__ void uf_unite(int32_t *parent, int32_t a, int32_t b) 
 }
 
 // Walks the tree for the CORE neighbours of q, tight nodes settled as a whole: calls
-// f(representative's row) for every tight node that has a core point within eps of q (its first core
+// f(representative's slot) for every tight node that has a core point within eps of q (its first core
 // point stands for all of them) and for every core point within eps reached as a leaf.  `own_slot`
 // (or -1) names q's own sorted slot: the tight node holding it is skipped.
-// `settled(row)` may say that the group a tight node's first core point stands for needs no look
+// `settled(slot)` may say that the group a tight node's first core point stands for needs no look
 // (the union kernel: already in my set), sparing the distance tests and the probe.
 template <typename S, typename F>
 __device__ __forceinline__ void for_each_core_group(const DbArgs &a, const LbvhPoint &q, int32_t own_slot, S settled, F f,
@@ -151,14 +152,14 @@ __device__ __forceinline__ void for_each_core_group(const DbArgs &a, const LbvhP
           ref = bvh.rope_node[ref];
           continue;
         }
-        if (!probing && settled(bvh.prim_id[s])) {
+        if (!probing && settled(s)) {
           ref = bvh.rope_node[ref];
           continue;
         }
         float far2, near2;
         box_dist2(nd, q, far2, near2);
         if (far2 <= a.eps_in2) {  // every point of the node is within eps
-          f(probing ? probe_rep : bvh.prim_id[s]);
+          f(probing ? probe_rep : s);
           ref = probing ? probe_exit : bvh.rope_node[ref];
           probe_rep = -1;
           continue;
@@ -168,7 +169,7 @@ __device__ __forceinline__ void for_each_core_group(const DbArgs &a, const LbvhP
           continue;
         }
         if (!probing) {
-          probe_rep = bvh.prim_id[s];
+          probe_rep = s;
           probe_exit = bvh.rope_node[ref];
         }
       }
@@ -185,7 +186,7 @@ __device__ __forceinline__ void for_each_core_group(const DbArgs &a, const LbvhP
             probe_rep = -1;
             continue;
           }
-          f(bvh.prim_id[slot]);
+          f(slot);
         }
       }
       ref = bvh.rope_leaf[slot];
@@ -193,8 +194,25 @@ __device__ __forceinline__ void for_each_core_group(const DbArgs &a, const LbvhP
   }
 }
 
+// the wave's flagged lanes take consecutive places of a list (one atomic per wave)
+__device__ __forceinline__ void db_append(bool flag, int32_t value, int32_t *list, unsigned long long *count) {
+  const unsigned long long m = __ballot(flag);
+  if (!m) return;
+  const int lane = threadIdx.x & 63, first = __ffsll((long long)m) - 1;
+  unsigned long long base = 0;
+  if (lane == first) base = atomicAdd(count, (unsigned long long)__popcll(m));
+  base = __shfl(base, first);
+  if (flag) list[base + __popcll(m & ((1ull << lane) - 1ull))] = value;
+}
+
+// Core flags.  Every point first looks at its GROUP, the first tight node on its own root path (db_group_kernel): its
+// points are pairwise within eps, so if it holds minPts of them the point is core without looking any further.  (Listing the
+// points that do have to look and walking for them with full waves, as the label pass does, was tried: on BASELINE config 3
+// they are a fifth of all points, a full wave waits for the longest of 64 walks instead of the longest of a dozen, and the
+// pass took 2.2 ms instead of 1.45.)
 __device__ __forceinline__ void db_core_body(const DbArgs &a, int32_t t, uint32_t &node_tests, uint32_t &point_tests) {
   const LbvhView &bvh = a.bvh;
+  a.parent[t] = t;
   if (a.keep_core && a.core_sorted[t]) return;
   const LbvhPoint q = bvh.points[t];
   int32_t cnt = 0;
@@ -203,8 +221,6 @@ __device__ __forceinline__ void db_core_body(const DbArgs &a, int32_t t, uint32_
   const float r = a.eps_wide;
   int32_t ref = bvh.root;
   if (!a.want_counts || a.group_of) {
-    // the first tight node on my own root path -- my GROUP (db_group_kernel): its points are pairwise within eps, so
-    // if it holds minPts of them I am core without looking any further
     int32_t node = bvh.root, first = t;
     while (node >= 0) {
       const LbvhNode nd = bvh.nodes[node];
@@ -251,12 +267,11 @@ __device__ __forceinline__ void db_core_body(const DbArgs &a, int32_t t, uint32_
   }
   const uint8_t is_core = cnt >= a.min_pts;
   a.core_sorted[t] = is_core;
-  // results and the union-find are indexed by ROW (the point's position in the caller's buffer,
-  // prim_id of the sorted slot), not by the id an engine built with tknnBuildIds reports
+  // results are indexed by ROW (the point's position in the caller's buffer, prim_id of the sorted
+  // slot), not by the id an engine built with tknnBuildIds reports; the union-find by sorted slot
   const int32_t row = bvh.prim_id[t];
   if (a.core) a.core[row] = is_core;
   if (a.counts) a.counts[row] = cnt;
-  a.parent[row] = row;
 }
 
 __global__ void __launch_bounds__(kDbBlock) db_core_kernel(DbArgs a) {
@@ -296,10 +311,9 @@ __device__ __forceinline__ void db_union_body(const DbArgs &a, int32_t t, unsign
                                               uint32_t &point_tests) {
   const LbvhView &bvh = a.bvh;
   const LbvhPoint q = bvh.points[t];
-  const int32_t row = bvh.prim_id[t];
   // the first tight node on my own root path: its core points are one cluster, held together by its
   // first core point, which also stands for me in the unions below
-  int32_t mine = row;
+  int32_t mine = t;
   int32_t node = bvh.root;
   while (node >= 0) {
     const LbvhNode nd = bvh.nodes[node];
@@ -307,8 +321,8 @@ __device__ __forceinline__ void db_union_body(const DbArgs &a, int32_t t, unsign
     if (node_is_tight(nd, a.eps_in2)) {
       const int32_t s = a.next_core[lbvh_first(node, nd.other)];  // <= t: I am core and inside
       if (s != t) {
-        mine = bvh.prim_id[s];
-        uf_unite(a.parent, row, mine);
+        mine = s;
+        uf_unite(a.parent, t, mine);
       }
       break;
     }
@@ -336,7 +350,7 @@ __device__ __forceinline__ void db_union_body(const DbArgs &a, int32_t t, unsign
         return true;
       },
       [&](int32_t other) {
-        if (other == mine || other == row) return;
+        if (other == mine || other == t) return;
         unsigned long long key;
         unsigned long long *slot = slot_of(other, key);
         if (*(volatile unsigned long long *)slot == key) return;
@@ -406,7 +420,7 @@ __global__ void __launch_bounds__(kDbBlock) db_group_kernel(DbArgs a, int32_t *g
   const bool leads = g >= 0 || g == ~t;
   const int32_t first = leads ? t : ~g;
   const int32_t s = a.next_core[first];
-  if (a.core_sorted[t] && s != t && !(a.diag & 4)) uf_unite(a.parent, bvh.prim_id[t], bvh.prim_id[s]);  // s < t: both core, one group
+  if (a.core_sorted[t] && s != t && !(a.diag & 4)) uf_unite(a.parent, t, s);  // s < t: both core, one group
   int32_t out = LBVH_END;
   if (leads) {
     const int32_t last = g >= 0 ? lbvh_last(g, bvh.nodes[g].other) : t;
@@ -485,9 +499,9 @@ __global__ void __launch_bounds__(kDbBlock) db_group_union_kernel(DbArgs a, cons
     return false;
   };
   int waiting = 0;
-  // what the lanes have collected: three rounds of loads for all of it, then one group after the other
+  // what the lanes have collected: two rounds of loads for all of it, then one group after the other
   auto settle = [&]() {
-    int32_t b_core[kDbBuf], b_last[kDbBuf], row[kDbBuf], par[kDbBuf];
+    int32_t b_core[kDbBuf], b_last[kDbBuf], par[kDbBuf];
 #pragma unroll
     for (int w = 0; w < kDbBuf; w++) {
       b_core[w] = 0x7fffffff;
@@ -501,20 +515,15 @@ __global__ void __launch_bounds__(kDbBlock) db_group_union_kernel(DbArgs a, cons
     }
 #pragma unroll
     for (int w = 0; w < kDbBuf; w++) {
-      row[w] = -1;
-      if (b_core[w] <= b_last[w]) row[w] = bvh.prim_id[b_core[w]];  // else: no core point in it (or no entry)
-    }
-#pragma unroll
-    for (int w = 0; w < kDbBuf; w++) {
       par[w] = -1;
-      if (row[w] >= 0) par[w] = uf_load(a.parent + row[w]);
+      if (b_core[w] <= b_last[w]) par[w] = uf_load(a.parent + b_core[w]);  // else: no core point in it (or no entry)
     }
 #pragma unroll
     for (int w = 0; w < kDbBuf; w++) {
-      if (row[w] < 0 || (a.diag & 2)) continue;
+      if (b_core[w] > b_last[w] || (a.diag & 2)) continue;
       // a parent pointer never leaves its set: pointing at my root means "in my set" without walking to the root
       if (par[w] == my_root) continue;
-      const int32_t other = row[w];
+      const int32_t other = b_core[w];
       if (uf_find(a.parent, other) == my_root) continue;
       my_root = uf_find(a.parent, my_root);  // my root may have been hooked under another meanwhile
       if (uf_find(a.parent, other) == my_root) continue;
@@ -573,7 +582,7 @@ __global__ void __launch_bounds__(kDbBlock) db_group_union_kernel(DbArgs a, cons
         a_first = a_last = ~G;
       }
       a_core = a.next_core[a_first];  // <= a_last: listed groups have a core point
-      mine = bvh.prim_id[a_core];
+      mine = a_core;
       my_root = uf_find(a.parent, mine);
     }
     // nothing before the packet's earliest group end can lie after any of its groups
@@ -663,42 +672,67 @@ __global__ void __launch_bounds__(kDbBlock) db_group_union_kernel(DbArgs a, cons
   db_add_stats(a.stats + 2, blk_stats, node_tests, point_tests);
 }
 
-// after the unions: point every core at its root and flag roots for the ranking scan
-__global__ void __launch_bounds__(kDbBlock) db_flatten_kernel(DbArgs a, int32_t *is_root) {
+// after the unions: every core slot points at its root, and the root learns the smallest ROW of its cluster -- clusters are
+// numbered by that (the spec: ascending smallest core index).  A wave's slots mostly share one root: one atomic per wave
+// and root, not per point.
+__global__ void __launch_bounds__(kDbBlock) db_flatten_kernel(DbArgs a) {
   const int32_t t = blockIdx.x * kDbBlock + threadIdx.x;
-  if (t >= a.bvh.n) return;
-  const int32_t id = a.bvh.prim_id[t];
-  int32_t flag = 0;
-  if (a.core_sorted[t]) {
-    const int32_t root = uf_find(a.parent, id);
-    flag = root == id;
-    a.labels[id] = root;  // temporary: root index, replaced by its rank in db_label_kernel
+  const bool core = t < a.bvh.n && a.core_sorted[t];
+  int32_t root = -1, row = 0x7fffffff;
+  if (core) {
+    root = uf_find(a.parent, t);
+    __hip_atomic_store(a.parent + t, root, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    row = a.bvh.prim_id[t];
   }
-  is_root[id] = flag;
+  const int lane = threadIdx.x & 63;
+  for (unsigned long long todo = __ballot(core); todo;) {
+    const int j = __ffsll((long long)todo) - 1;
+    const int32_t r_j = __shfl(root, j);
+    const bool same = core && root == r_j;
+    int32_t m = same ? row : 0x7fffffff;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = min(m, __shfl_xor(m, off));
+    if (lane == j) atomicMin(a.min_row + r_j, m);
+    todo &= ~__ballot(same);
+  }
+}
+// roots flag their cluster's smallest row; an exclusive scan over the rows then numbers the clusters
+__global__ void __launch_bounds__(kDbBlock) db_root_kernel(DbArgs a, int32_t *is_first_row) {
+  const int32_t t = blockIdx.x * kDbBlock + threadIdx.x;
+  if (t < a.bvh.n && a.core_sorted[t] && a.parent[t] == t) is_first_row[a.min_row[t]] = 1;
 }
 
-__global__ void __launch_bounds__(kDbBlock) db_label_kernel(DbArgs a) {
+// Labels in two launches, like the core flags: core points take their cluster's number; the others -- few, and scattered
+// over the waves -- are listed and look for the lowest-numbered cluster among their core neighbours with full waves.
+__global__ void __launch_bounds__(kDbBlock) db_label_kernel(DbArgs a, int32_t *pending, unsigned long long *n_pending) {
+  const int32_t t = blockIdx.x * kDbBlock + threadIdx.x;
+  bool walk = false;
+  if (t < a.bvh.n) {
+    if (a.core_sorted[t])
+      a.labels[a.bvh.prim_id[t]] = a.rank[a.min_row[uf_find(a.parent, t)]];  // (mostly one step: db_flatten_kernel has pointed the slots at their roots)
+    else
+      walk = true;
+  }
+  db_append(walk, t, pending, n_pending);
+}
+__global__ void __launch_bounds__(kDbBlock) db_label_walk_kernel(DbArgs a, const int32_t *pending, const unsigned long long *n_pending) {
   __shared__ unsigned long long blk_stats[2];
   if (threadIdx.x < 2) blk_stats[threadIdx.x] = 0ull;
   __syncthreads();
   uint32_t node_tests = 0, point_tests = 0;
-  const int32_t t = blockIdx.x * kDbBlock + threadIdx.x;
-  if (t < a.bvh.n) {
+  const long long total = (long long)*n_pending;
+  for (long long i = (long long)blockIdx.x * kDbBlock + threadIdx.x; i < total; i += (long long)gridDim.x * kDbBlock) {
+    const int32_t t = pending[i];
     const LbvhPoint q = a.bvh.points[t];
-    const int32_t row = a.bvh.prim_id[t];
-    int32_t root = -1;
-    if (a.core_sorted[t]) {
-      root = uf_find(a.parent, row);
-    } else {
-      for_each_core_group(
-          a, q, -1, [](int32_t) { return false; },
-          [&](int32_t other) {
-            const int32_t r = uf_find(a.parent, other);
-            if (root < 0 || r < root) root = r;
-          },
-          node_tests, point_tests);
-    }
-    a.labels[row] = root < 0 ? -1 : a.rank[root];
+    int32_t first_row = -1;  // of my cluster: the smallest over the clusters of my core neighbours (the lowest label)
+    for_each_core_group(
+        a, q, -1, [](int32_t) { return false; },
+        [&](int32_t other) {
+          const int32_t m = a.min_row[uf_find(a.parent, other)];
+          if (first_row < 0 || m < first_row) first_row = m;
+        },
+        node_tests, point_tests);
+    a.labels[a.bvh.prim_id[t]] = first_row < 0 ? -1 : a.rank[first_row];
   }
   db_add_stats(a.stats + 4, blk_stats, node_tests, point_tests);
 }
@@ -724,7 +758,7 @@ __global__ void __launch_bounds__(kDbBlock) db_assign_kernel(DbArgs a, const int
       for_each_core_group(
           a, q, -1, [](int32_t) { return false; },
           [&](int32_t other) {
-            const int32_t l = core_label[other];  // a tight node's core points share one label: its first stands for all
+            const int32_t l = core_label[a.bvh.prim_id[other]];  // a tight node's core points share one label: its first stands for all
             if (best < 0 || l < best) best = l;
           },
           node_tests, point_tests);
@@ -799,8 +833,9 @@ __global__ void __launch_bounds__(kDbBlock) db_noise_probe_kernel(DbArgs a, uint
 void Engine::dbscan(float eps, int min_pts, int32_t *d_labels, uint8_t *d_core, int32_t *d_counts,
                     tknnDbscanInfo *info, hipStream_t s, const int32_t *core_label) {
   const int64_t n = bvh_.size();
-  // scratch: core flags per slot, parent, root flags, ranks
-  const size_t need = (((size_t)n * (1 + 4 + 4 + 4 + 4)) + 16 + 255) / 256 * 256;  // + next_core, + two sentinels
+  // scratch: core flags per slot, parent, root flags, ranks, next_core (+ two sentinels), smallest rows
+  const size_t min_row_at = ((size_t)n * 17 + 8 + 15) / 16 * 16;
+  const size_t need = (min_row_at + (size_t)n * 4 + 255) / 256 * 256;
   size_t scan_bytes = 0, select_bytes = 0;
   OWLMI_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, (int32_t *)nullptr, (int32_t *)nullptr, (int)n, s));
   OWLMI_HIP(hipcub::DeviceSelect::If(nullptr, select_bytes, (int32_t *)nullptr, (int32_t *)nullptr, (unsigned long long *)nullptr, (int)n, DbIsGroup(), s));
@@ -825,6 +860,7 @@ void Engine::dbscan(float eps, int min_pts, int32_t *d_labels, uint8_t *d_core, 
   a.rank = (int32_t *)(ws + (size_t)n * 8);  // n + 1 entries
   int32_t *next_core = (int32_t *)(ws + (size_t)n * 12 + 4);  // n + 1 entries
   a.core_sorted = (uint8_t *)(ws + (size_t)n * 16 + 8);
+  a.min_row = (int32_t *)(ws + min_row_at);
   a.next_core = next_core;
   a.eps_in2 = eps * eps * (1.0f - 1e-5f);
   a.eps_out2 = eps * eps * (1.0f + 1e-5f);
@@ -838,7 +874,8 @@ void Engine::dbscan(float eps, int min_pts, int32_t *d_labels, uint8_t *d_core, 
   a.group_of = core_label || per_point ? nullptr : d_labels;
   const unsigned blocks = (unsigned)((n + kDbBlock - 1) / kDbBlock);
   a.stats = counters_;  // [0..5]: node / point tests of the three traversal kernels
-  OWLMI_HIP(hipMemsetAsync(counters_, 0, 8 * sizeof(unsigned long long), s));
+  OWLMI_HIP(hipMemsetAsync(counters_, 0, 20 * sizeof(unsigned long long), s));  // ... [19]: length of the label pass's list
+  const unsigned walk_grid = blocks < 2048u ? blocks : 2048u;  // grid-stride over lists whose lengths only the device knows
   hipEvent_t e0 = ev_a_, e1 = ev_b_;
   OWLMI_HIP(hipEventRecord(e0, s));
   if (core_label) {
@@ -921,19 +958,23 @@ void Engine::dbscan(float eps, int min_pts, int32_t *d_labels, uint8_t *d_core, 
     hipLaunchKernelGGL(db_group_union_kernel, dim3(grid), dim3(kDbBlock), 0, s, a, groups, n_groups, n_groups + 1, n_groups + 9);
   }
   OWLMI_HIP(hipEventRecord(ev_e_, s));
-  hipLaunchKernelGGL(db_flatten_kernel, dim3(blocks), dim3(kDbBlock), 0, s, a, is_root);
+  OWLMI_HIP(hipMemsetAsync(a.min_row, 0x7f, (size_t)n * sizeof(int32_t), s));  // 0x7f7f7f7f: above every row
+  hipLaunchKernelGGL(db_flatten_kernel, dim3(blocks), dim3(kDbBlock), 0, s, a);
+  OWLMI_HIP(hipMemsetAsync(is_root, 0, (size_t)n * sizeof(int32_t), s));  // (the group list lived here)
+  hipLaunchKernelGGL(db_root_kernel, dim3(blocks), dim3(kDbBlock), 0, s, a, is_root);
   OWLMI_HIP(hipGetLastError());
   OWLMI_HIP(hipcub::DeviceScan::ExclusiveSum(scan_tmp, scan_bytes, is_root, a.rank, (int)n, s));
+  // number of clusters = rank[n-1] + is_root[n-1] (read now: the flags' place is the label pass's list next)
+  int32_t last[2] = {0, 0};
+  OWLMI_HIP(hipMemcpyAsync(&last[0], a.rank + (n - 1), 4, hipMemcpyDeviceToHost, s));
+  OWLMI_HIP(hipMemcpyAsync(&last[1], is_root + (n - 1), 4, hipMemcpyDeviceToHost, s));
   OWLMI_HIP(hipEventRecord(ev_f_, s));
-  hipLaunchKernelGGL(db_label_kernel, dim3(blocks), dim3(kDbBlock), 0, s, a);
+  hipLaunchKernelGGL(db_label_kernel, dim3(blocks), dim3(kDbBlock), 0, s, a, is_root, counters_ + 19);
+  hipLaunchKernelGGL(db_label_walk_kernel, dim3(walk_grid), dim3(kDbBlock), 0, s, a, is_root, counters_ + 19);
   OWLMI_HIP(hipGetLastError());
   OWLMI_HIP(hipEventRecord(e1, s));
   OWLMI_HIP(hipMemcpyAsync(h_counters_, counters_, 9 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
   OWLMI_HIP(hipMemcpyAsync(h_counters_ + 9, counters_ + 17, sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
-  // number of clusters = rank[n-1] + is_root[n-1]
-  int32_t last[2] = {0, 0};
-  OWLMI_HIP(hipMemcpyAsync(&last[0], a.rank + (n - 1), 4, hipMemcpyDeviceToHost, s));
-  OWLMI_HIP(hipMemcpyAsync(&last[1], is_root + (n - 1), 4, hipMemcpyDeviceToHost, s));
   OWLMI_HIP(hipStreamSynchronize(s));
   if (!per_point && h_counters_[9] != 0 && !db_force_point_) {
     // a packet's walk ran out of stack (a tree some 250 levels deep): the whole call again with the per-point unions
@@ -1015,7 +1056,7 @@ void Engine::dbscan_auto(float eps0, int min_pts, double max_noise, int max_roun
     a.eps_wide = eps * 1.000001f;
     a.eps_in2 = eps * eps * (1.0f - 1e-5f);
     a.eps_out2 = eps * eps * (1.0f + 1e-5f);
-    OWLMI_HIP(hipMemsetAsync(counters_, 0, 8 * sizeof(unsigned long long), s));
+    OWLMI_HIP(hipMemsetAsync(counters_, 0, 20 * sizeof(unsigned long long), s));
     hipLaunchKernelGGL(db_core_kernel, dim3(blocks), dim3(kDbBlock), 0, s, a);
     {
       int32_t *flag = a.rank, *pos = a.rank;
