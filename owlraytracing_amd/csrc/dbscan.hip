@@ -30,6 +30,10 @@
 
 #include <cstring>
 
+#ifndef TKNN_DIAG_BUILD
+#define TKNN_DIAG_BUILD 0  // make DIAG=1 -> libowl_mi355x_diag.so: TKNN_DB_DIAG switches parts of the union pass off (times only)
+#endif
+
 namespace owlmi {
 namespace {
 
@@ -57,7 +61,7 @@ struct DbArgs {
   int32_t *group_of;  // per sorted slot, written by the core-flag kernel (see db_group_kernel); null: not wanted
   int chunk;  // packets per chunk dealt to an XCD (db_group_union_kernel)
   float reach, near_lo2, near_hi2;  // this pass of db_group_union_kernel: groups whose nearest faces are near_lo2 < d^2 <= near_hi2 apart, reach >= sqrt(near_hi2)
-  int diag;  // TKNN_DB_DIAG (measurements only; results are wrong when set): 1 = no probes, 2 = no unions between groups, 4 = none inside groups
+  int diag;  // TKNN_DB_DIAG, diagnostic library only (results are wrong when set): 1 = no probes, 2 = no unions between groups, 4 = none inside groups
 };
 
 // a workgroup's counts into the kernel's two counters: wave sums, one LDS atomic per wave, one global
@@ -854,7 +858,7 @@ void Engine::dbscan(float eps, int min_pts, int32_t *d_labels, uint8_t *d_core, 
   a.min_pts = min_pts;
   a.want_counts = d_counts != nullptr;
   a.keep_core = 0;
-  a.diag = getenv("TKNN_DB_DIAG") ? atoi(getenv("TKNN_DB_DIAG")) : 0;
+  a.diag = (TKNN_DIAG_BUILD && getenv("TKNN_DB_DIAG")) ? atoi(getenv("TKNN_DB_DIAG")) : 0;  // the diagnostic library only
   a.parent = (int32_t *)ws;
   int32_t *is_root = (int32_t *)(ws + (size_t)n * 4);
   a.rank = (int32_t *)(ws + (size_t)n * 8);  // n + 1 entries

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""RT-DBSCAN at BASELINE config 3 under a few TKNN_DB_DIAG / TKNN_DBSCAN_UNION settings (GPU box; measurements only)."""
+"""RT-DBSCAN at BASELINE config 3 under a few TKNN_DB_DIAG / chunk / grid / split settings (GPU box; measurements only).
+TKNN_DB_DIAG needs the diagnostic library: make -C owlraytracing_amd/csrc DIAG=1, OWL_MI355X_LIB=.../libowl_mi355x_diag.so."""
 import os
 import sys
 

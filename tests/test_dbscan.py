@@ -139,6 +139,39 @@ def test_group_unions_equal_point_unions(monkeypatch):
 
 
 @pytest.mark.gpu
+def test_hip_dbscan_degenerate_sets():
+    """Shapes the group machinery has to survive: one or two points, every point the same (one group of 50 000), an eps
+    that makes the ROOT a tight node, NaN coordinates, minPts 1, and a tree without a single core point."""
+    from owlraytracing_amd.trueknn import TrueKNN
+    rng = np.random.default_rng(21)
+    same = np.tile(np.float32([[0.3, 0.4, 0.5]]), (50_000, 1))
+    with_nan = datasets.uniform3d(5000, seed=22)
+    with_nan[rng.choice(5000, 40, replace=False), rng.integers(0, 3, 40)] = np.nan
+    two_blobs = np.concatenate([same[:3000], same[:3000] + np.float32(0.25)])
+    cases = [
+        ("one_point", np.float32([[0.1, 0.2, 0.3]]), 0.01, 1),
+        ("two_points_apart", np.float32([[0.1, 0.2, 0.3], [0.9, 0.9, 0.9]]), 0.01, 1),
+        ("two_points_close", np.float32([[0.1, 0.2, 0.3], [0.1, 0.2, 0.3005]]), 0.01, 2),
+        ("all_the_same", same, 0.01, 4),
+        ("root_is_tight", datasets.uniform3d(3000, seed=23), 4.0, 5),
+        ("nan_coordinates", with_nan, 0.05, 3),
+        ("two_stacks_of_duplicates", two_blobs[rng.permutation(len(two_blobs))], 0.01, 10),
+        ("no_core_point", datasets.uniform3d(2000, seed=24), 1e-4, 2),
+    ]
+    eng = TrueKNN()
+    for name, xyz, eps, min_pts in cases:
+        xyz = np.ascontiguousarray(xyz, dtype=np.float32)
+        eps = float(np.float32(eps))
+        ref = oracle.dbscan(xyz, eps, min_pts)
+        eng.build(xyz)
+        got = eng.dbscan(eps, min_pts)
+        assert np.array_equal(got["labels"].cpu().numpy(), ref["labels"]), name
+        assert np.array_equal(got["core"].cpu().numpy(), ref["core"]), name
+        assert got["info"]["clusters"] == ref["clusters"], name
+    eng.close()
+
+
+@pytest.mark.gpu
 def test_hip_dbscan_argument_errors():
     from owlraytracing_amd import _lib
     from owlraytracing_amd.trueknn import TrueKNN
