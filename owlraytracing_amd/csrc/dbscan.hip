@@ -61,7 +61,7 @@ struct DbArgs {
   int32_t *group_of;  // per sorted slot, written by the core-flag kernel (see db_group_kernel); null: not wanted
   int chunk;  // packets per chunk dealt to an XCD (db_group_union_kernel)
   float reach, near_lo2, near_hi2;  // this pass of db_group_union_kernel: groups whose nearest faces are near_lo2 < d^2 <= near_hi2 apart, reach >= sqrt(near_hi2)
-  int diag;  // TKNN_DB_DIAG, diagnostic library only (results are wrong when set): 1 = no probes, 2 = no unions between groups, 4 = none inside groups
+  int diag;  // TKNN_DB_DIAG, diagnostic library only (results are wrong when set): 1 = no probes, 2 = no unions between groups, 4 = none inside groups, 8 = walk lengths on stderr, 16 = report a stack overflow (the result is right: the call falls back)
 };
 
 // a workgroup's counts into the kernel's two counters: wave sums, one LDS atomic per wave, one global
@@ -450,7 +450,10 @@ __global__ void __launch_bounds__(kDbBlock) db_group_kernel(DbArgs a, int32_t *g
 // the stack walk needs some 40 rounds of loads per packet; with the popped nodes tested against the packet's bounding box
 // instead of its 64 groups, a packet across a jump of the Z-curve walked half the tree: one wave, 4 ms.)
 constexpr int kDbBuf = 8;
-constexpr int kDbStack = 1024;  // references per wave; popped one at a time (depth first) when fewer than 256 places are left
+#ifndef TKNN_DB_STACK
+#define TKNN_DB_STACK 1024  // (a build with 320 exercises the depth-first mode and the overflow fallback: tests)
+#endif
+constexpr int kDbStack = TKNN_DB_STACK;  // references per wave; popped one at a time (depth first) when fewer than 256 places are left
 constexpr int kDbCand = 64;     // the boxes popped in one round, per wave
 struct DbCand {
   float lo[3];
@@ -476,6 +479,7 @@ __global__ void __launch_bounds__(kDbBlock) db_group_union_kernel(DbArgs a, cons
   __syncthreads();
   const LbvhView &bvh = a.bvh;
   uint32_t node_tests = 0, point_tests = 0;
+  if ((a.diag & 16) && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(overflow, 1ull);  // diagnostic library: take the host's fallback
   const long long total = (long long)*n_groups;
   const long long packets = (total + 63) / 64;
   const int lane = threadIdx.x & 63;
