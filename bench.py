@@ -74,10 +74,11 @@ def cpu_baseline_trueknn(xyz, k, r0):
     return out, ref, q
 
 
-def cpu_baseline_dbscan(xyz, eps, min_pts, budget_s=30.0):
+def cpu_baseline_dbscan(xyz, eps, min_pts, budget_s=90.0):
     """the spec's grid DBSCAN on all host cores (oracle.dbscan_threaded).  The whole set
-    if a timed 5 % slab says it fits the budget, else the largest leading share of the points that does (clusters
-    of a mixture keep their shape, the density falls with the share: the rate is then an upper bound)."""
+    if a timed 5 % slab says it fits the budget (config 3 takes 40 s on the 128 threads of a GPU box: the budget is
+    generous because the whole set is also the bench's parity check), else the largest leading share of the points
+    that does (clusters of a mixture keep their shape, the density falls with the share: the rate is then an upper bound)."""
     import oracle
 
     n = len(xyz)

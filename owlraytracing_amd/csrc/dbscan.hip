@@ -60,8 +60,9 @@ struct DbArgs {
   unsigned long long *stats;
   int32_t *group_of;  // per sorted slot, written by the core-flag kernel (see db_group_kernel); null: not wanted
   int chunk;  // packets per chunk dealt to an XCD (db_group_union_kernel)
+  int scan_budget;  // steps the quick scan of a probe may take before the subtrees are asked (db_group_union_kernel)
   float reach, near_lo2, near_hi2;  // this pass of db_group_union_kernel: groups whose nearest faces are near_lo2 < d^2 <= near_hi2 apart, reach >= sqrt(near_hi2)
-  int diag;  // TKNN_DB_DIAG, diagnostic library only (results are wrong when set): 1 = no probes, 2 = no unions between groups, 4 = none inside groups, 8 = walk lengths on stderr, 16 = report a stack overflow (the result is right: the call falls back)
+  int diag;  // TKNN_DB_DIAG, diagnostic library only (results are wrong when set): 1 = no probes, 2 = no unions between groups, 4 = none inside groups, 8 = walk lengths on stderr, 16 = report a stack overflow (the result is right: the call falls back), 32 = probes by scanning only (the result is right)
 };
 
 // a workgroup's counts into the kernel's two counters: wave sums, one LDS atomic per wave, one global
@@ -492,19 +493,81 @@ __global__ void __launch_bounds__(kDbBlock) db_group_union_kernel(DbArgs a, cons
   float alo[3], ahi[3];
   int32_t a_last = 0, a_core = 0, mine = 0, my_root = 0;
   // B = a tight node or a single leaf with box blo..bhi, first core slot b_core, last slot b_last: an edge?
-  auto probe = [&](const float *blo, const float *bhi, int32_t b_core, int32_t b_last) -> bool {
+  // A scan: my core points that are within eps of B's box against B's core points, until the first hit.  With a budget
+  // (steps of either loop) it is the first thing tried -- between neighbouring groups of a dense region the first pairs
+  // looked at are within eps -- and gives up undecided (-1) when the budget is spent; without one it is exact (1 / 0).
+  auto probe = [&](const float *blo, const float *bhi, int32_t b_core, int32_t b_last, int budget) -> int {
     for (int32_t i = a_core; i <= a_last; i = a.next_core[i + 1]) {
+      if (budget-- == 0) return -1;
       const LbvhPoint p = bvh.points[i];
       const float bx = fmaxf(fmaxf(blo[0] - p.x, p.x - bhi[0]), 0.f), by = fmaxf(fmaxf(blo[1] - p.y, p.y - bhi[1]), 0.f),
                   bz = fmaxf(fmaxf(blo[2] - p.z, p.z - bhi[2]), 0.f);
       if (bx * bx + by * by + bz * bz > a.eps_out2) continue;  // nothing of B within eps of p
       for (int32_t j = b_core; j <= b_last; j = a.next_core[j + 1]) {
+        if (budget-- == 0) return -1;
         const LbvhPoint q = bvh.points[j];
         point_tests++;
-        if (knn_sqrt(knn_dist2(q.x, q.y, q.z, p.x, p.y, p.z)) <= a.eps) return true;
+        if (knn_sqrt(knn_dist2(q.x, q.y, q.z, p.x, p.y, p.z)) <= a.eps) return 1;
       }
     }
-    return false;
+    return 0;
+  };
+  // The same question answered down the two groups' own subtrees: a pair of sub-nodes is dropped when its nearest
+  // faces are beyond eps or one side has no core point, settles the question when its farthest corners are within eps,
+  // and is split otherwise (the side with the longer diagonal) -- a few dozen steps where the scan above may look at
+  // every point of a group of thousands before it meets one near the other group (50 M heavy-tailed 2-D points with
+  // duplicates: 21 ms for the union pass with the scan alone).  1 / 0: edge / none; -1: the stack is full, scan instead.
+  int32_t a_ref = 0;
+  auto tree_probe = [&](int32_t b_ref) -> int {
+    constexpr int kDepth = 24;
+    volatile int32_t sx[kDepth], sy[kDepth];  // (volatile: private memory, not 48 registers)
+    int top = 0;
+    sx[top] = a_ref, sy[top] = b_ref, top++;
+    while (top > 0) {
+      top--;
+      const int32_t x = sx[top], y = sy[top];
+      float xlo[3], xhi[3], ylo[3], yhi[3];
+      int32_t x_first, x_last, y_first, y_last, x_split = 0, y_split = 0;
+      if (x >= 0) {
+        const LbvhNode nd = bvh.nodes[x];
+        for (int c = 0; c < 3; c++) xlo[c] = nd.lo[c], xhi[c] = nd.hi[c];
+        x_first = lbvh_first(x, nd.other), x_last = lbvh_last(x, nd.other), x_split = nd.split;
+      } else {
+        const LbvhPoint q = bvh.points[~x];
+        xlo[0] = xhi[0] = q.x, xlo[1] = xhi[1] = q.y, xlo[2] = xhi[2] = q.z;
+        x_first = x_last = ~x;
+      }
+      if (y >= 0) {
+        const LbvhNode nd = bvh.nodes[y];
+        for (int c = 0; c < 3; c++) ylo[c] = nd.lo[c], yhi[c] = nd.hi[c];
+        y_first = lbvh_first(y, nd.other), y_last = lbvh_last(y, nd.other), y_split = nd.split;
+      } else {
+        const LbvhPoint q = bvh.points[~y];
+        ylo[0] = yhi[0] = q.x, ylo[1] = yhi[1] = q.y, ylo[2] = yhi[2] = q.z;
+        y_first = y_last = ~y;
+      }
+      if (a.next_core[x_first] > x_last || a.next_core[y_first] > y_last) continue;  // a side without a core point
+      float far2, near2;
+      box_box_dist2(xlo, xhi, ylo, yhi, far2, near2);
+      if (near2 > a.eps_out2) continue;
+      if (far2 <= a.eps_in2) return 1;
+      if (x < 0 && y < 0) {  // two core points within rounding of eps: the spec's arithmetic decides
+        point_tests++;
+        if (knn_sqrt(knn_dist2(ylo[0], ylo[1], ylo[2], xlo[0], xlo[1], xlo[2])) <= a.eps) return 1;
+        continue;
+      }
+      if (top + 2 > kDepth) return -1;
+      const float dx = (xhi[0] - xlo[0]) * (xhi[0] - xlo[0]) + (xhi[1] - xlo[1]) * (xhi[1] - xlo[1]) + (xhi[2] - xlo[2]) * (xhi[2] - xlo[2]);
+      const float dy = (yhi[0] - ylo[0]) * (yhi[0] - ylo[0]) + (yhi[1] - ylo[1]) * (yhi[1] - ylo[1]) + (yhi[2] - ylo[2]) * (yhi[2] - ylo[2]);
+      if (x >= 0 && (y < 0 || dx >= dy)) {
+        sx[top] = x_first == x_split ? ~x_split : x_split, sy[top] = y, top++;
+        sx[top] = x_last == x_split + 1 ? ~(x_split + 1) : x_split + 1, sy[top] = y, top++;
+      } else {
+        sx[top] = x, sy[top] = y_first == y_split ? ~y_split : y_split, top++;
+        sx[top] = x, sy[top] = y_last == y_split + 1 ? ~(y_split + 1) : y_split + 1, top++;
+      }
+    }
+    return 0;
   };
   int waiting = 0;
   // what the lanes have collected: two rounds of loads for all of it, then one group after the other
@@ -526,26 +589,36 @@ __global__ void __launch_bounds__(kDbBlock) db_group_union_kernel(DbArgs a, cons
       par[w] = -1;
       if (b_core[w] <= b_last[w]) par[w] = uf_load(a.parent + b_core[w]);  // else: no core point in it (or no entry)
     }
+    uint32_t todo = 0;  // collected groups that have a core point and do not point at my root
 #pragma unroll
-    for (int w = 0; w < kDbBuf; w++) {
-      if (b_core[w] > b_last[w] || (a.diag & 2)) continue;
-      // a parent pointer never leaves its set: pointing at my root means "in my set" without walking to the root
-      if (par[w] == my_root) continue;
-      const int32_t other = b_core[w];
+    for (int w = 0; w < kDbBuf; w++)
+      if (b_core[w] <= b_last[w] && par[w] != my_root) todo |= 1u << w;  // (a parent pointer never leaves its set: pointing at my root means "in my set")
+    if (a.diag & 2) todo = 0;
+    // the rest one after the other (not unrolled: the probe's private stack would be kept once per copy)
+    while (todo) {
+      const int w = __ffs((int)todo) - 1;
+      todo &= todo - 1u;
+      const int32_t B = my_ref[w * kDbBlock], packed = my_other[w * kDbBlock];
+      const int32_t end = B >= 0 ? B : ~B, o = packed & 0x7fffffff;
+      const int32_t other_last = max(end, o), other = a.next_core[min(end, o)];  // its first core slot stands for the group
       if (uf_find(a.parent, other) == my_root) continue;
       my_root = uf_find(a.parent, my_root);  // my root may have been hooked under another meanwhile
       if (uf_find(a.parent, other) == my_root) continue;
-      bool edge = my_other[w * kDbBlock] < 0;
+      bool edge = packed < 0;
       if (!edge && !(a.diag & 1)) {
-        const int32_t B = my_ref[w * kDbBlock];
+        // a few pairs by scanning, then down the two subtrees, and the whole scan if that runs out of stack
+        float blo[3], bhi[3];
         if (B >= 0) {
           const LbvhNode nd = bvh.nodes[B];
-          edge = probe(nd.lo, nd.hi, b_core[w], b_last[w]);
+          for (int c = 0; c < 3; c++) blo[c] = nd.lo[c], bhi[c] = nd.hi[c];
         } else {
           const LbvhPoint q = bvh.points[~B];
-          const float b[3] = {q.x, q.y, q.z};
-          edge = probe(b, b, b_core[w], b_last[w]);
+          blo[0] = bhi[0] = q.x, blo[1] = bhi[1] = q.y, blo[2] = bhi[2] = q.z;
         }
+        int found = probe(blo, bhi, other, other_last, a.scan_budget);
+        if (found < 0 && !(a.diag & 32)) found = tree_probe(B);
+        if (found < 0) found = probe(blo, bhi, other, other_last, -1);
+        edge = found > 0;
       }
       if (edge) {
         uf_unite(a.parent, mine, other);
@@ -579,6 +652,7 @@ __global__ void __launch_bounds__(kDbBlock) db_group_union_kernel(DbArgs a, cons
     alo[0] = alo[1] = alo[2] = ahi[0] = ahi[1] = ahi[2] = 0.f;
     if (have) {
       const int32_t G = groups[g];
+      a_ref = G;
       if (G >= 0) {
         const LbvhNode nd = bvh.nodes[G];
         for (int c = 0; c < 3; c++) alo[c] = nd.lo[c], ahi[c] = nd.hi[c];
@@ -934,6 +1008,7 @@ void Engine::dbscan(float eps, int min_pts, int32_t *d_labels, uint8_t *d_core, 
     unsigned long long *n_groups = counters_ + 8;
     OWLMI_HIP(hipMemsetAsync(n_groups, 0, 10 * sizeof(unsigned long long), s));  // ... and the count of stack overflows in [17]
     a.chunk = getenv("TKNN_DB_CHUNK") ? std::max(1, atoi(getenv("TKNN_DB_CHUNK"))) : 64;
+    a.scan_budget = getenv("TKNN_DB_SCAN") ? std::max(0, atoi(getenv("TKNN_DB_SCAN"))) : 12;
     hipLaunchKernelGGL(db_group_kernel, dim3(blocks), dim3(kDbBlock), 0, s, a, group_at);
     OWLMI_HIP(hipcub::DeviceSelect::If(scan_tmp, scan_bytes, group_at, groups, n_groups, (int)n, DbIsGroup(), s));
     // persistent lanes: as many workgroups as the device holds at once (the list's length is known on the device only)
