@@ -1,3 +1,6 @@
+#!/usr/bin/env python3
+"""GPU box: per-kernel times of RT-DBSCAN on 50 M heavy-tailed 2-D points (BASELINE config 5's kind of set) at a few eps.
+    python scripts/taxi_probe.py [eps ...]"""
 import sys, os
 sys.path.insert(0, os.getcwd())
 import torch, numpy as np
