@@ -451,8 +451,13 @@ __global__ void __launch_bounds__(kDbBlock) db_group_kernel(DbArgs a, int32_t *g
 // the stack walk needs some 40 rounds of loads per packet; with the popped nodes tested against the packet's bounding box
 // instead of its 64 groups, a packet across a jump of the Z-curve walked half the tree: one wave, 4 ms.)
 constexpr int kDbBuf = 8;
+#ifndef TKNN_DB_UNION_BLOCK
+#define TKNN_DB_UNION_BLOCK 128  // threads per workgroup of the group-union kernel (its waves are independent)
+#define TKNN_DB_WAVES 5          // waves per SIMD its register allocation aims at
+#endif
+constexpr int kDbUnionBlock = TKNN_DB_UNION_BLOCK;
 #ifndef TKNN_DB_STACK
-#define TKNN_DB_STACK 1024  // (a build with 320 exercises the depth-first mode and the overflow fallback: tests)
+#define TKNN_DB_STACK 512  // (a build with 320 exercises the depth-first mode and the overflow fallback: tests)
 #endif
 constexpr int kDbStack = TKNN_DB_STACK;  // references per wave; popped one at a time (depth first) when fewer than 256 places are left
 constexpr int kDbCand = 64;     // the boxes popped in one round, per wave
@@ -467,13 +472,13 @@ __device__ __forceinline__ void db_wave_sync() {
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
-__global__ void __launch_bounds__(kDbBlock) db_group_union_kernel(DbArgs a, const int32_t *groups, const unsigned long long *n_groups,
+__global__ void __launch_bounds__(kDbUnionBlock) __attribute__((amdgpu_waves_per_eu(TKNN_DB_WAVES))) db_group_union_kernel(DbArgs a, const int32_t *groups, const unsigned long long *n_groups,
                                                                   unsigned long long *next_packet, unsigned long long *overflow) {
   __shared__ unsigned long long blk_stats[2];
-  __shared__ int32_t buf_ref[kDbBuf * kDbBlock];    // [entry][thread]: the group's node (or ~slot of a single point)
-  __shared__ int32_t buf_other[kDbBuf * kDbBlock];  // the other end of its slot range | far-corners-within-eps << 31
-  __shared__ int32_t stack_all[(kDbBlock / 64) * kDbStack];
-  __shared__ __align__(16) DbCand cand_all[(kDbBlock / 64) * kDbCand];
+  __shared__ int32_t buf_ref[kDbBuf * kDbUnionBlock];    // [entry][thread]: the group's node (or ~slot of a single point)
+  __shared__ int32_t buf_other[kDbBuf * kDbUnionBlock];  // the other end of its slot range | far-corners-within-eps << 31
+  __shared__ int32_t stack_all[(kDbUnionBlock / 64) * kDbStack];
+  __shared__ __align__(16) DbCand cand_all[(kDbUnionBlock / 64) * kDbCand];
   int32_t *stack = stack_all + (threadIdx.x >> 6) * kDbStack;
   DbCand *cand = cand_all + (threadIdx.x >> 6) * kDbCand;
   if (threadIdx.x < 2) blk_stats[threadIdx.x] = 0ull;
@@ -578,7 +583,7 @@ __global__ void __launch_bounds__(kDbBlock) db_group_union_kernel(DbArgs a, cons
       b_core[w] = 0x7fffffff;
       b_last[w] = -1;
       if (w < waiting) {
-        const int32_t x = my_ref[w * kDbBlock], o = my_other[w * kDbBlock] & 0x7fffffff;
+        const int32_t x = my_ref[w * kDbUnionBlock], o = my_other[w * kDbUnionBlock] & 0x7fffffff;
         const int32_t end = x >= 0 ? x : ~x;
         b_last[w] = max(end, o);
         b_core[w] = a.next_core[min(end, o)];
@@ -598,7 +603,7 @@ __global__ void __launch_bounds__(kDbBlock) db_group_union_kernel(DbArgs a, cons
     while (todo) {
       const int w = __ffs((int)todo) - 1;
       todo &= todo - 1u;
-      const int32_t B = my_ref[w * kDbBlock], packed = my_other[w * kDbBlock];
+      const int32_t B = my_ref[w * kDbUnionBlock], packed = my_other[w * kDbUnionBlock];
       const int32_t end = B >= 0 ? B : ~B, o = packed & 0x7fffffff;
       const int32_t other_last = max(end, o), other = a.next_core[min(end, o)];  // its first core slot stands for the group
       if (uf_find(a.parent, other) == my_root) continue;
@@ -722,8 +727,8 @@ __global__ void __launch_bounds__(kDbBlock) db_group_union_kernel(DbArgs a, cons
         float far2, near2;
         box_box_dist2(alo, ahi, e.lo, e.hi, far2, near2);
         if (hit && e_first > a_last && near2 <= a.near_hi2 && near2 > a.near_lo2) {
-          my_ref[waiting * kDbBlock] = e.ref;
-          my_other[waiting * kDbBlock] = e.other | (far2 <= a.eps_in2 ? (int32_t)0x80000000 : 0);
+          my_ref[waiting * kDbUnionBlock] = e.ref;
+          my_other[waiting * kDbUnionBlock] = e.other | (far2 <= a.eps_in2 ? (int32_t)0x80000000 : 0);
           waiting++;
         }
         if (__ballot(waiting == kDbBuf) != 0ull) settle();
@@ -1016,7 +1021,7 @@ void Engine::dbscan(float eps, int min_pts, int32_t *d_labels, uint8_t *d_core, 
       int per_cu = 0, dev = 0;
       hipDeviceProp_t prop;
       if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 256 * 4;
-      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)db_group_union_kernel, kDbBlock, 0) != hipSuccess) per_cu = 4;
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)db_group_union_kernel, kDbUnionBlock, 0) != hipSuccess) per_cu = 4;
       return prop.multiProcessorCount * std::max(1, per_cu);
     }();
     unsigned grid = blocks < (unsigned)resident ? blocks : (unsigned)resident;
@@ -1032,13 +1037,13 @@ void Engine::dbscan(float eps, int min_pts, int32_t *d_labels, uint8_t *d_core, 
     OWLMI_HIP(hipEventRecord(ev_d_, s));
     if (split < 1.f) {
       union_launches = 2;
-      hipLaunchKernelGGL(db_group_union_kernel, dim3(grid), dim3(kDbBlock), 0, s, a, groups, n_groups, n_groups + 1, n_groups + 9);
+      hipLaunchKernelGGL(db_group_union_kernel, dim3(grid), dim3(kDbUnionBlock), 0, s, a, groups, n_groups, n_groups + 1, n_groups + 9);
       OWLMI_HIP(hipMemsetAsync(n_groups + 1, 0, 8 * sizeof(unsigned long long), s));
       a.near_lo2 = a.near_hi2;
     }
     a.near_hi2 = a.eps_out2;
     a.reach = a.eps_wide;
-    hipLaunchKernelGGL(db_group_union_kernel, dim3(grid), dim3(kDbBlock), 0, s, a, groups, n_groups, n_groups + 1, n_groups + 9);
+    hipLaunchKernelGGL(db_group_union_kernel, dim3(grid), dim3(kDbUnionBlock), 0, s, a, groups, n_groups, n_groups + 1, n_groups + 9);
   }
   OWLMI_HIP(hipEventRecord(ev_e_, s));
   OWLMI_HIP(hipMemsetAsync(a.min_row, 0x7f, (size_t)n * sizeof(int32_t), s));  // 0x7f7f7f7f: above every row
