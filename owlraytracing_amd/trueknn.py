@@ -192,7 +192,7 @@ class TrueKNN:
                                             ctypes.c_void_p(core.data_ptr()),
                                             None if counts is None else ctypes.c_void_p(counts.data_ptr()),
                                             ctypes.byref(info), self._stream()))
-        out = {"labels": labels, "core": core.bool(), "info": info.as_dict()}
+        out = {"labels": labels, "core": core.view(torch.bool), "info": info.as_dict()}
         if counts is not None:
             out["counts"] = counts
         return out
@@ -209,7 +209,7 @@ class TrueKNN:
             _lib.check(self._lib.tknnDbscanAuto(self._h, ctypes.c_float(eps0), int(min_pts), ctypes.c_double(max_noise), int(max_rounds),
                                                 ctypes.c_void_p(labels.data_ptr()), ctypes.c_void_p(core.data_ptr()),
                                                 ctypes.byref(info), self._stream()))
-        return {"labels": labels, "core": core.bool(), "info": info.as_dict()}
+        return {"labels": labels, "core": core.view(torch.bool), "info": info.as_dict()}
 
     def dbscan_assign(self, eps, core_label):
         """Last step of DBSCAN with labels decided by the caller: ``core_label`` (n,) int32, >= 0 for
