@@ -230,6 +230,10 @@ typedef struct {
 } tknnDbscanAutoInfo;
 TKNN_API int tknnDbscanAuto(tknnEngine e, float eps0, int min_pts, double max_noise, int max_rounds, int32_t *d_labels,
                             uint8_t *d_core, tknnDbscanAutoInfo *info, void *stream);
+/* One growth round's question alone, for a caller that runs the loop itself (the sharded driver: the tiles' halos grow with
+ * eps): d_noise[row] = 1 if the point would be labelled -1 by tknnDbscan(eps, min_pts) -- it is not core and has no core
+ * point within eps --, 0 otherwise; no clusters are built.  *noise_count (may be NULL) = how many. */
+TKNN_API int tknnDbscanNoise(tknnEngine e, float eps, int min_pts, uint8_t *d_noise, int64_t *noise_count, void *stream);
 
 /* Test / debug export of the tree to host memory (any pointer may be NULL):
  *   nodes      (n-1) x 8 dwords {lo[3], split, hi[3], other}   (include/owl/lbvh_device.h)

@@ -915,7 +915,63 @@ __global__ void __launch_bounds__(kDbBlock) db_noise_probe_kernel(DbArgs a, uint
   db_add_stats(a.stats + 6, blk_noise, still, 0u);
 }
 
+// per-slot flags to the caller's rows
+__global__ void __launch_bounds__(kDbBlock) db_rows_kernel(DbArgs a, const uint8_t *by_slot, uint8_t *by_row) {
+  const int32_t t = blockIdx.x * kDbBlock + threadIdx.x;
+  if (t < a.bvh.n) by_row[a.bvh.prim_id[t]] = by_slot[t];
+}
+
 }  // namespace
+
+// tknnDbscanNoise: one growth round of the auto-eps loop without the loop -- core flags, then the noise probe of every
+// point that is not core.  Returns the number of noise points; d_noise is indexed by row.
+int64_t Engine::dbscan_noise(float eps, int min_pts, uint8_t *d_noise, hipStream_t s) {
+  const int64_t n = bvh_.size();
+  size_t scan_bytes = 0;
+  OWLMI_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, (int32_t *)nullptr, (int32_t *)nullptr, (int)n, s));
+  const size_t need = (((size_t)n * (4 + 4 + 4 + 4 + 1 + 1)) + 32 + 255) / 256 * 256;  // as dbscan_auto
+  if (need + scan_bytes > wave_ws_bytes_) {
+    if (wave_ws_) (void)hipFree(wave_ws_);
+    wave_ws_ = nullptr;
+    OWLMI_HIP(hipMalloc(&wave_ws_, need + scan_bytes));
+    wave_ws_bytes_ = need + scan_bytes;
+  }
+  char *ws = (char *)wave_ws_;
+  DbArgs a;
+  std::memset(&a, 0, sizeof a);
+  a.bvh = bvh_.view();
+  a.min_pts = min_pts;
+  a.eps = eps;
+  a.eps_wide = eps * 1.000001f;
+  a.eps_in2 = eps * eps * (1.0f - 1e-5f);
+  a.eps_out2 = eps * eps * (1.0f + 1e-5f);
+  a.parent = (int32_t *)ws;
+  int32_t *core_rank = (int32_t *)(ws + (size_t)n * 4);
+  a.rank = (int32_t *)(ws + (size_t)n * 8);                   // n + 1 entries: flags, then positions
+  int32_t *next_core = (int32_t *)(ws + (size_t)n * 12 + 4);  // n + 1 entries
+  a.core_sorted = (uint8_t *)(ws + (size_t)n * 16 + 8);
+  uint8_t *noise = a.core_sorted + n;
+  a.next_core = next_core;
+  a.stats = counters_;
+  void *scan_tmp = ws + need;
+  const unsigned blocks = (unsigned)((n + kDbBlock - 1) / kDbBlock), blocks1 = (unsigned)((n + 1 + kDbBlock - 1) / kDbBlock);
+  OWLMI_HIP(hipMemsetAsync(counters_, 0, 20 * sizeof(unsigned long long), s));
+  hipLaunchKernelGGL(db_core_kernel, dim3(blocks), dim3(kDbBlock), 0, s, a);
+  {
+    int32_t *flag = a.rank, *pos = a.rank;
+    hipLaunchKernelGGL(db_core_flag_kernel, dim3(blocks), dim3(kDbBlock), 0, s, a, flag);
+    OWLMI_HIP(hipcub::DeviceScan::ExclusiveSum(scan_tmp, scan_bytes, flag, core_rank, (int)n, s));
+    OWLMI_HIP(hipMemsetAsync(pos, 0x7f, ((size_t)n + 1) * sizeof(int32_t), s));
+    hipLaunchKernelGGL(db_core_pos_kernel, dim3(blocks), dim3(kDbBlock), 0, s, a, core_rank, pos);
+    hipLaunchKernelGGL(db_next_core_kernel, dim3(blocks1), dim3(kDbBlock), 0, s, a, core_rank, pos, next_core);
+  }
+  hipLaunchKernelGGL(db_noise_probe_kernel, dim3(blocks), dim3(kDbBlock), 0, s, a, noise, 1);
+  hipLaunchKernelGGL(db_rows_kernel, dim3(blocks), dim3(kDbBlock), 0, s, a, noise, d_noise);
+  OWLMI_HIP(hipGetLastError());
+  OWLMI_HIP(hipMemcpyAsync(h_counters_, counters_, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+  OWLMI_HIP(hipStreamSynchronize(s));
+  return (int64_t)h_counters_[6];
+}
 
 void Engine::dbscan(float eps, int min_pts, int32_t *d_labels, uint8_t *d_core, int32_t *d_counts,
                     tknnDbscanInfo *info, hipStream_t s, const int32_t *core_label) {

@@ -806,6 +806,20 @@ int tknnDbscanAuto(tknnEngine e, float eps0, int min_pts, double max_noise, int 
   return rc;
 }
 
+int tknnDbscanNoise(tknnEngine e, float eps, int min_pts, uint8_t *d_noise, int64_t *noise_count, void *stream) {
+  if (!e || !d_noise) {
+    g_last_error = "tknnDbscanNoise: engine or flag pointer is NULL";
+    return TKNN_E_ARG;
+  }
+  return guarded_on(e, [&] {
+    if (!e->impl.built()) throw owlmi::ArgError{TKNN_E_STATE, "tknnDbscanNoise: call tknnBuild first"};
+    if (!(eps > 0.f) || !std::isfinite(eps)) throw owlmi::ArgError{TKNN_E_ARG, "tknnDbscanNoise: eps must be finite and > 0"};
+    if (min_pts < 1) throw owlmi::ArgError{TKNN_E_ARG, "tknnDbscanNoise: min_pts must be >= 1"};
+    const int64_t count = e->impl.dbscan_noise(eps, min_pts, d_noise, (hipStream_t)stream);
+    if (noise_count) *noise_count = count;
+  });
+}
+
 int tknnExportTree(tknnEngine e, void *nodes, int32_t *rope_node, int32_t *rope_leaf, int32_t *prim_id,
                    void *stream) {
   if (!e) {

@@ -59,6 +59,7 @@ class Engine {
   void dbscan(float eps, int min_pts, int32_t *d_labels, uint8_t *d_core, int32_t *d_counts, tknnDbscanInfo *info,
               hipStream_t s, const int32_t *core_label = nullptr);
   // "eps auto-grown" (BASELINE config 5; spec: oracle/dbscan_oracle.c dbref_dbscan_auto)
+  int64_t dbscan_noise(float eps, int min_pts, uint8_t *d_noise, hipStream_t s);  // tknnDbscanNoise
   void dbscan_auto(float eps0, int min_pts, double max_noise, int max_rounds, int32_t *d_labels, uint8_t *d_core,
                    tknnDbscanAutoInfo *info, hipStream_t s);
   bool built() const { return bvh_.built(); }

@@ -120,6 +120,7 @@ class ShardedTrueKNN:
         self.engine = engine_factory(self.device)
         self._engine_factory = engine_factory
         self.db_engine = None   # second engine over own + halo points (dbscan)
+        self._db_cache = None   # (eps, what _db_setup returned for it)
         # first halo radius = start_radius * 2**halo_levels; None: from the density of the set, the level
         # at which a box is expected to hold 32 k points (nearly every query has finished by then, so
         # one exchange and one solve do; stragglers still widen the halo and go again)
@@ -189,6 +190,7 @@ class ShardedTrueKNN:
         order = torch.argsort(mycodes)
         got, mycodes = got[order].contiguous(), mycodes[order]
         self.points = got[:, :3].contiguous()
+        self._db_cache = None
         self.ids = got[:, 3].contiguous().view(torch.int32)
         self._rows = got  # 16-byte wire rows: x y z id-bits
         n_local = torch.tensor([len(self.points)], dtype=torch.int64, device=dev)
@@ -403,7 +405,7 @@ class ShardedTrueKNN:
         return info
 
     # ---- RT-DBSCAN over the tiles (last row) -----------------------------------
-    def dbscan(self, eps, min_pts):
+    def dbscan(self, eps, min_pts, _reuse_setup=False):
         """DBSCAN of the whole set with the single-GPU spec (oracle/dbscan_oracle.c): returns
         dict(labels (m,) int32, core (m,) bool) for the points this rank owns (``self.ids`` order) and
         info(clusters, rounds, halo_points).  Clusters are numbered by ascending smallest core id, so
@@ -418,20 +420,7 @@ class ShardedTrueKNN:
         comm, dev = self.comm, self.device
         eps32 = float(np.float32(eps))
         m = len(self.points)
-        blocks = self._halo_blocks(2.0 * eps32)
-        got = comm.exchange_rows(blocks, 4, torch.float32, dev)
-        got[comm.rank] = got[comm.rank][:0]
-        counts_in = [len(g) for g in got]
-        halo = torch.cat(got, dim=0)
-        # the rows I sent, as positions in my own arrays (values travel in the same order later)
-        id_sorted, id_perm = torch.sort(self.ids.long())
-        sent_local = [id_perm[torch.searchsorted(id_sorted, b[:, 3].contiguous().view(torch.int32).long())]
-                      if len(b) else torch.zeros(0, dtype=torch.long, device=dev) for b in blocks]
-        pts = torch.cat([self.points, halo[:, :3]], dim=0).contiguous()
-        ids = torch.cat([self.ids, halo[:, 3].contiguous().view(torch.int32)], dim=0).contiguous()
-        if self.db_engine is None:
-            self.db_engine = self._engine_factory(dev)
-        self.db_engine.build(pts, ids)
+        halo, counts_in, sent_local, ids = self._db_setup(eps32, reuse=_reuse_setup)
         local = self.db_engine.dbscan(eps32, min_pts)
         core = local["core"].to(dev).bool()
         comp = local["labels"].to(dev).long()
@@ -478,19 +467,48 @@ class ShardedTrueKNN:
         info = {"clusters": int(len(everyone)), "rounds": rounds, "halo_points": int(len(halo))}
         return {"labels": labels[:m].to(dev), "core": core[:m], "info": info}
 
+    def _db_setup(self, eps32, reuse=False):
+        """The engine over my tile plus a halo of radius 2 eps (see dbscan).  ``reuse``: the auto-eps loop's last growth
+        round and the clustering that follows it use one exchange and one tree; every other call does its own."""
+        if reuse and self._db_cache is not None and self._db_cache[0] == eps32:
+            return self._db_cache[1]
+        comm, dev = self.comm, self.device
+        blocks = self._halo_blocks(2.0 * eps32)
+        got = comm.exchange_rows(blocks, 4, torch.float32, dev)
+        got[comm.rank] = got[comm.rank][:0]
+        counts_in = [len(g) for g in got]
+        halo = torch.cat(got, dim=0)
+        # the rows I sent, as positions in my own arrays (values travel in the same order later)
+        id_sorted, id_perm = torch.sort(self.ids.long())
+        sent_local = [id_perm[torch.searchsorted(id_sorted, b[:, 3].contiguous().view(torch.int32).long())]
+                      if len(b) else torch.zeros(0, dtype=torch.long, device=dev) for b in blocks]
+        pts = torch.cat([self.points, halo[:, :3]], dim=0).contiguous()
+        ids = torch.cat([self.ids, halo[:, 3].contiguous().view(torch.int32)], dim=0).contiguous()
+        if self.db_engine is None:
+            self.db_engine = self._engine_factory(dev)
+        self.db_engine.build(pts, ids)
+        self._db_cache = (eps32, (halo, counts_in, sent_local, ids))
+        return self._db_cache[1]
+
     def dbscan_auto(self, eps0, min_pts, max_noise=0.05, max_rounds=32):
         """RT-DBSCAN with an auto-grown eps over the tiles (spec: oracle/dbscan_oracle.c, dbref_dbscan_auto): rounds of the
-        sharded DBSCAN above with eps doubling (fp32, hostCode.cpp:321) until at most floor(max_noise * n_total) points of
-        the WHOLE set are noise -- one 8-byte all-reduce per round; the final round's halo has radius 2 * eps_final."""
+        eps doubling (fp32, hostCode.cpp:321) until at most floor(max_noise * n_total) points of the WHOLE set are noise.
+        A growth round exchanges the 2-eps halo, builds the tile's tree and counts its own noise points
+        (tknnDbscanNoise) -- one 8-byte all-reduce per round; clusters are built once, at the final eps."""
         comm, dev = self.comm, self.device
         bound = int(np.floor(float(max_noise) * self.n_total))
         eps = np.float32(eps0)
+        m = len(self.points)
         for t in range(int(max_rounds)):
-            r = self.dbscan(float(eps), min_pts)
-            noise = torch.tensor([int((r["labels"] < 0).sum().item())], dtype=torch.int64, device=dev)
+            # a growth round only counts: core flags are exact for my own points inside the 2-eps halo, and a point of
+            # mine is noise iff it is not core and has no core point within eps -- no clusters, no label exchange
+            self._db_setup(float(eps))
+            flags = self.db_engine.dbscan_noise(float(eps), min_pts)["noise"]
+            noise = torch.tensor([int(flags[:m].sum().item())], dtype=torch.int64, device=dev)
             comm.all_reduce(noise, dist.ReduceOp.SUM)
-            r["info"].update({"rounds": t + 1, "eps": float(eps), "noise": int(noise.item())})
             if int(noise.item()) <= bound:
+                r = self.dbscan(float(eps), min_pts, _reuse_setup=True)  # (same eps: the round's halo and tree)
+                r["info"].update({"rounds": t + 1, "eps": float(eps), "noise": int(noise.item())})
                 return r
             eps = np.float32(eps * np.float32(2))
         raise _lib.TknnError(-4, "max_rounds doublings of eps did not bring the noise under the bound")

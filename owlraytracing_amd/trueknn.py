@@ -211,6 +211,17 @@ class TrueKNN:
                                                 ctypes.byref(info), self._stream()))
         return {"labels": labels, "core": core.view(torch.bool), "info": info.as_dict()}
 
+    def dbscan_noise(self, eps, min_pts):
+        """Which points tknnDbscan(eps, min_pts) would label -1, without building clusters (tknnDbscanNoise: one growth
+        round of the auto-eps loop for a caller that runs the loop itself).  dict(noise (n,) bool, count)."""
+        torch = self._torch
+        with torch.cuda.device(self.device):
+            noise = torch.empty((self.n,), dtype=torch.uint8, device=self.device)
+            count = ctypes.c_int64(0)
+            _lib.check(self._lib.tknnDbscanNoise(self._h, ctypes.c_float(eps), int(min_pts), ctypes.c_void_p(noise.data_ptr()),
+                                                 ctypes.byref(count), self._stream()))
+        return {"noise": noise.view(torch.bool), "count": int(count.value)}
+
     def dbscan_assign(self, eps, core_label):
         """Last step of DBSCAN with labels decided by the caller: ``core_label`` (n,) int32, >= 0 for
         core points.  Returns labels (n,) int32: core points keep theirs, the others take the smallest

@@ -58,6 +58,12 @@ class CheckerEngine:
         return {"labels": torch.from_numpy(r["labels"].astype(np.int32)), "core": torch.from_numpy(r["core"].astype(bool)),
                 "info": {"clusters": int(r["clusters"])}}
 
+    def dbscan_noise(self, eps, min_pts):
+        import oracle
+        r = oracle.dbscan(self.pts, eps, min_pts)
+        flags = r["labels"] < 0
+        return {"noise": torch.from_numpy(flags), "count": int(flags.sum())}
+
     def dbscan_assign(self, eps, core_label):
         from scipy.spatial import cKDTree
         lab = np.asarray(core_label.cpu().numpy(), np.int32)

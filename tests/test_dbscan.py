@@ -313,6 +313,26 @@ def test_auto_grown_eps_spec():
 
 
 @pytest.mark.gpu
+def test_hip_dbscan_noise_flags_equal_the_spec():
+    """tknnDbscanNoise (one growth round of the auto-eps loop, for the sharded driver): the points tknnDbscan would label
+    -1, by row -- also on an engine built with ids, and with NaN coordinates (noise by definition)."""
+    from owlraytracing_amd.trueknn import TrueKNN
+    xyz = datasets.pad_to_3d(datasets.taxi_like2d(30_000, components=10, seed=31))
+    xyz[[5, 77, 4000], [0, 1, 2]] = np.nan
+    eng = TrueKNN()
+    for eps, min_pts, ids in [(0.0005, 4, None), (0.004, 6, np.arange(len(xyz), dtype=np.int32)[::-1].copy() + 1000)]:
+        eps = float(np.float32(eps))
+        ref = oracle.dbscan(xyz, eps, min_pts)
+        eng.build(xyz, ids)
+        got = eng.dbscan_noise(eps, min_pts)
+        assert np.array_equal(got["noise"].cpu().numpy(), ref["labels"] < 0)
+        assert got["count"] == int((ref["labels"] < 0).sum())
+    with pytest.raises(Exception):
+        eng.dbscan_noise(-1.0, 4)
+    eng.close()
+
+
+@pytest.mark.gpu
 def test_hip_dbscan_auto_equals_the_spec():
     from owlraytracing_amd import _lib
     from owlraytracing_amd.trueknn import TrueKNN
