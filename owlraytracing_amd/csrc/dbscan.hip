@@ -66,8 +66,11 @@ struct DbArgs {
 };
 
 // a workgroup's counts into the kernel's two counters: wave sums, one LDS atomic per wave, one global
-// atomic per workgroup (every thread of the workgroup must call it)
+// atomic per workgroup (every thread of the workgroup must call it).  `stats` = a.stats + 2 * (which kernel): the counters
+// are kept in 32 stripes of 8 words, a workgroup adds to the stripe of its index, the host sums them.
+constexpr int kDbStripes = 32;
 __device__ __forceinline__ void db_add_stats(unsigned long long *stats, unsigned long long *blk, uint32_t nodes, uint32_t points) {
+  stats += (blockIdx.x & (kDbStripes - 1)) * 8;
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) {
     nodes += __shfl_xor(nodes, off);
@@ -759,6 +762,13 @@ __global__ void __launch_bounds__(kDbUnionBlock) __attribute__((amdgpu_waves_per
   db_add_stats(a.stats + 2, blk_stats, node_tests, point_tests);
 }
 
+// min_row[root] = min(min_row[root], row).  The value only falls, so a read that finds it at or below `row` settles the matter
+// without an atomic: a cluster of millions of points would otherwise queue an atomic per wave on ONE address (50 M 2-D
+// points, one giant cluster: 6 ms for the pass; with the read first, a handful of atomics get through).
+__device__ __forceinline__ void db_min_row(int32_t *cell, int32_t row) {
+  if (__hip_atomic_load(cell, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > row) atomicMin(cell, row);
+}
+
 // after the unions: every core slot points at its root, and the root learns the smallest ROW of its cluster -- clusters are
 // numbered by that (the spec: ascending smallest core index).  A wave's slots mostly share one root: one atomic per wave
 // and root, not per point.
@@ -772,16 +782,22 @@ __global__ void __launch_bounds__(kDbBlock) db_flatten_kernel(DbArgs a) {
     row = a.bvh.prim_id[t];
   }
   const int lane = threadIdx.x & 63;
-  for (unsigned long long todo = __ballot(core); todo;) {
+  // the wave's two most common cases first -- one root for all its slots, or two -- as one atomic each; slots of further
+  // roots (sparse regions: many small clusters per wave, hardly two slots on one address) send their own
+  bool pending = core;
+  for (int round = 0; round < 2; round++) {
+    const unsigned long long todo = __ballot(pending);
+    if (!todo) break;
     const int j = __ffsll((long long)todo) - 1;
     const int32_t r_j = __shfl(root, j);
-    const bool same = core && root == r_j;
+    const bool same = pending && root == r_j;
     int32_t m = same ? row : 0x7fffffff;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) m = min(m, __shfl_xor(m, off));
-    if (lane == j) atomicMin(a.min_row + r_j, m);
-    todo &= ~__ballot(same);
+    if (lane == j) db_min_row(a.min_row + r_j, m);
+    pending = pending && !same;
   }
+  if (pending) db_min_row(a.min_row + root, row);
 }
 // roots flag their cluster's smallest row; an exclusive scan over the rows then numbers the clusters
 __global__ void __launch_bounds__(kDbBlock) db_root_kernel(DbArgs a, int32_t *is_first_row) {
@@ -923,6 +939,17 @@ __global__ void __launch_bounds__(kDbBlock) db_rows_kernel(DbArgs a, const uint8
 
 }  // namespace
 
+// the work counters of the launches so far: the stripes to the host (synchronises the stream), summed into h_counters_[0..7]
+void Engine::db_read_stats(hipStream_t s) {
+  OWLMI_HIP(hipMemcpyAsync(h_counters_ + 16, counters_ + kCounters, kDbStripes * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+  OWLMI_HIP(hipStreamSynchronize(s));
+  for (int i = 0; i < 8; i++) {
+    unsigned long long sum = 0;
+    for (int st = 0; st < kDbStripes; st++) sum += h_counters_[16 + st * 8 + i];
+    h_counters_[i] = sum;
+  }
+}
+
 // tknnDbscanNoise: one growth round of the auto-eps loop without the loop -- core flags, then the noise probe of every
 // point that is not core.  Returns the number of noise points; d_noise is indexed by row.
 int64_t Engine::dbscan_noise(float eps, int min_pts, uint8_t *d_noise, hipStream_t s) {
@@ -952,10 +979,10 @@ int64_t Engine::dbscan_noise(float eps, int min_pts, uint8_t *d_noise, hipStream
   a.core_sorted = (uint8_t *)(ws + (size_t)n * 16 + 8);
   uint8_t *noise = a.core_sorted + n;
   a.next_core = next_core;
-  a.stats = counters_;
+  a.stats = counters_ + kCounters;  // striped (db_add_stats)
   void *scan_tmp = ws + need;
   const unsigned blocks = (unsigned)((n + kDbBlock - 1) / kDbBlock), blocks1 = (unsigned)((n + 1 + kDbBlock - 1) / kDbBlock);
-  OWLMI_HIP(hipMemsetAsync(counters_, 0, 20 * sizeof(unsigned long long), s));
+  OWLMI_HIP(hipMemsetAsync(counters_, 0, (kCounters + kDbStripes * 8) * sizeof(unsigned long long), s));
   hipLaunchKernelGGL(db_core_kernel, dim3(blocks), dim3(kDbBlock), 0, s, a);
   {
     int32_t *flag = a.rank, *pos = a.rank;
@@ -968,8 +995,7 @@ int64_t Engine::dbscan_noise(float eps, int min_pts, uint8_t *d_noise, hipStream
   hipLaunchKernelGGL(db_noise_probe_kernel, dim3(blocks), dim3(kDbBlock), 0, s, a, noise, 1);
   hipLaunchKernelGGL(db_rows_kernel, dim3(blocks), dim3(kDbBlock), 0, s, a, noise, d_noise);
   OWLMI_HIP(hipGetLastError());
-  OWLMI_HIP(hipMemcpyAsync(h_counters_, counters_, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
-  OWLMI_HIP(hipStreamSynchronize(s));
+  db_read_stats(s);
   return (int64_t)h_counters_[6];
 }
 
@@ -1016,8 +1042,8 @@ void Engine::dbscan(float eps, int min_pts, int32_t *d_labels, uint8_t *d_core, 
   // every point's group, for the union pass; kept in the caller's label array, which is written last
   a.group_of = core_label || per_point ? nullptr : d_labels;
   const unsigned blocks = (unsigned)((n + kDbBlock - 1) / kDbBlock);
-  a.stats = counters_;  // [0..5]: node / point tests of the three traversal kernels
-  OWLMI_HIP(hipMemsetAsync(counters_, 0, 20 * sizeof(unsigned long long), s));  // ... [19]: length of the label pass's list
+  a.stats = counters_ + kCounters;  // striped (db_add_stats); [0..5]: node / point tests of the three traversal kernels
+  OWLMI_HIP(hipMemsetAsync(counters_, 0, (kCounters + kDbStripes * 8) * sizeof(unsigned long long), s));  // ... [19]: length of the label pass's list
   const unsigned walk_grid = blocks < 2048u ? blocks : 2048u;  // grid-stride over lists whose lengths only the device knows
   hipEvent_t e0 = ev_a_, e1 = ev_b_;
   OWLMI_HIP(hipEventRecord(e0, s));
@@ -1043,8 +1069,7 @@ void Engine::dbscan(float eps, int min_pts, int32_t *d_labels, uint8_t *d_core, 
     OWLMI_HIP(hipGetLastError());
     OWLMI_HIP(hipEventRecord(e1, s));
     OWLMI_HIP(hipStreamSynchronize(s));
-    OWLMI_HIP(hipMemcpyAsync(h_counters_, counters_, 6 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
-    OWLMI_HIP(hipStreamSynchronize(s));
+    db_read_stats(s);
     if (info) {
       float ms = 0;
       OWLMI_HIP(hipEventElapsedTime(&ms, e0, e1));
@@ -1117,8 +1142,9 @@ void Engine::dbscan(float eps, int min_pts, int32_t *d_labels, uint8_t *d_core, 
   hipLaunchKernelGGL(db_label_walk_kernel, dim3(walk_grid), dim3(kDbBlock), 0, s, a, is_root, counters_ + 19);
   OWLMI_HIP(hipGetLastError());
   OWLMI_HIP(hipEventRecord(e1, s));
-  OWLMI_HIP(hipMemcpyAsync(h_counters_, counters_, 9 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
-  OWLMI_HIP(hipMemcpyAsync(h_counters_ + 9, counters_ + 17, sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+  OWLMI_HIP(hipMemcpyAsync(h_counters_ + 8, counters_ + 8, sizeof(unsigned long long), hipMemcpyDeviceToHost, s));   // groups
+  OWLMI_HIP(hipMemcpyAsync(h_counters_ + 9, counters_ + 17, sizeof(unsigned long long), hipMemcpyDeviceToHost, s));  // stack overflows
+  db_read_stats(s);
   OWLMI_HIP(hipStreamSynchronize(s));
   if (!per_point && h_counters_[9] != 0 && !db_force_point_) {
     // a packet's walk ran out of stack (a tree some 250 levels deep): the whole call again with the per-point unions
@@ -1186,7 +1212,7 @@ void Engine::dbscan_auto(float eps0, int min_pts, double max_noise, int max_roun
   a.core_sorted = (uint8_t *)(ws + (size_t)n * 16 + 8);
   uint8_t *noise = a.core_sorted + n;
   a.next_core = next_core;
-  a.stats = counters_;
+  a.stats = counters_ + kCounters;  // striped (db_add_stats)
   void *scan_tmp = ws + need;
   const unsigned blocks = (unsigned)((n + kDbBlock - 1) / kDbBlock), blocks1 = (unsigned)((n + 1 + kDbBlock - 1) / kDbBlock);
   OWLMI_HIP(hipMemsetAsync(a.core_sorted, 0, (size_t)n, s));
@@ -1200,7 +1226,7 @@ void Engine::dbscan_auto(float eps0, int min_pts, double max_noise, int max_roun
     a.eps_wide = eps * 1.000001f;
     a.eps_in2 = eps * eps * (1.0f - 1e-5f);
     a.eps_out2 = eps * eps * (1.0f + 1e-5f);
-    OWLMI_HIP(hipMemsetAsync(counters_, 0, 20 * sizeof(unsigned long long), s));
+    OWLMI_HIP(hipMemsetAsync(counters_, 0, (kCounters + kDbStripes * 8) * sizeof(unsigned long long), s));
     hipLaunchKernelGGL(db_core_kernel, dim3(blocks), dim3(kDbBlock), 0, s, a);
     {
       int32_t *flag = a.rank, *pos = a.rank;
@@ -1212,8 +1238,7 @@ void Engine::dbscan_auto(float eps0, int min_pts, double max_noise, int max_roun
     }
     hipLaunchKernelGGL(db_noise_probe_kernel, dim3(blocks), dim3(kDbBlock), 0, s, a, noise, t == 0 ? 1 : 0);
     OWLMI_HIP(hipGetLastError());
-    OWLMI_HIP(hipMemcpyAsync(h_counters_, counters_, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
-    OWLMI_HIP(hipStreamSynchronize(s));
+    db_read_stats(s);
     rounds = t + 1;
     noise_now = (int64_t)h_counters_[6];
     if (noise_now <= bound) {

@@ -60,6 +60,7 @@ class Engine {
               hipStream_t s, const int32_t *core_label = nullptr);
   // "eps auto-grown" (BASELINE config 5; spec: oracle/dbscan_oracle.c dbref_dbscan_auto)
   int64_t dbscan_noise(float eps, int min_pts, uint8_t *d_noise, hipStream_t s);  // tknnDbscanNoise
+  void db_read_stats(hipStream_t s);
   void dbscan_auto(float eps0, int min_pts, double max_noise, int max_rounds, int32_t *d_labels, uint8_t *d_core,
                    tknnDbscanAutoInfo *info, hipStream_t s);
   bool built() const { return bvh_.built(); }
@@ -100,6 +101,9 @@ class Engine {
   int32_t *tie_list_ = nullptr;  // the first kTieListCap flagged slots, in the order the kernels met them
   uint8_t *tie_ = nullptr;  // per sorted slot: 0, or 1 + the level at which the query finished with exact-distance ties in reach of its row
   int64_t state_cap_ = 0;
+  // counters_: kCounters words (knn_device.h) + kDbStripes x 8 words of RT-DBSCAN's work counters, striped over the workgroups
+  // (dbscan.hip: a launch over 50 M points would otherwise queue 400 000 atomics on two addresses); h_counters_: 16 + the stripes
+  static constexpr int kDbStripes = 32;
   unsigned long long *counters_ = nullptr, *h_counters_ = nullptr;
   void *wave_ws_ = nullptr;
   size_t wave_ws_bytes_ = 0;
