@@ -158,6 +158,10 @@ def main():
     ap.add_argument("--min-pts", type=int, default=DB_MINPTS)
     ap.add_argument("--kernel", type=int, default=0, help="0 auto, 1 lane, 2 wave, 3 team")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-fb-leg", action="store_true",
+                    help="skip the api_layout_writeback solves (scripts/profile_gpu.sh: their launches write a 2.4 GB frameBuffer "
+                         "and must not be averaged into the PMC record of the benchmarked launch)")
+    ap.add_argument("--no-dbscan-leg", action="store_true", help="skip the RT-DBSCAN config-3 object of the default run")
     ap.add_argument("--sharded", action="store_true", help="use the Morton-tile / halo-exchange driver even for one rank")
     args = ap.parse_args()
 
@@ -274,7 +278,7 @@ def main():
         extra["halo_points"] = int(hp.item())
         extra["halo_exchanges"] = int(last.get("halo_exchanges", 1 if dbscan else 0))
         if dbscan:
-            extra["label_rounds"] = int(last.get("rounds", 0))
+            extra["label_rounds"] = int(last.get("label_rounds", last.get("rounds", 0)))
 
     ms_per_step = elapsed / args.steps * 1e3
     value = n_total * args.steps / elapsed
@@ -292,7 +296,7 @@ def main():
         line["tree_bytes"] = int(build_info["device_bytes"])
     if rank == 0:
         line["roofline"]["measured_copy_GBps"] = copy_bandwidth(dev)
-    if rank == 0 and not sharded and not dbscan:
+    if rank == 0 and not sharded and not dbscan and not args.no_fb_leg:
         # the reference's result layout (24-byte Neigh records, GeomTypes.h:22-28) is an artefact of
         # its API; its write-back cost is reported apart from the compact rows the step writes
         fb_ms = []
@@ -308,6 +312,11 @@ def main():
             "frameBuffer_bytes": 24 * k * n_total,
             "note": "one solve writing idx/dist/intersections AND the n*k 24-byte records the reference's host loop reads",
         }
+    if rank == 0 and not sharded and not dbscan and not args.no_dbscan_leg and n_total == N_POINTS:
+        # BASELINE config 3 in the same run (the driver only runs the default command): timed like the steps
+        # above, per-kernel rooflines, a sampled eps-ball parity check by the CPU spec
+        db_failed, line["dbscan_config3"] = dbscan_config3_leg(args, eng, dev)
+        failed = failed or db_failed
     if rank == 0 and not sharded and not args.no_cpu_baseline:
         if dbscan:
             cb, ref, m = cpu_baseline_dbscan(xyz_host, eps32, args.min_pts)
@@ -454,46 +463,126 @@ def dbscan_line(args, info, infos, value, ms_per_step, n_total, n_local, world, 
         line["roofline"] = {"bound": "hbm", "kernel": "db_group_union_kernel", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                             "frac": None, "traffic": None, "note": "per-kernel counters are reported by the single-GPU run"}
         return line
-    # the dominant traversal kernel of the call, by its own HIP-event time
-    names = {"core_ms": ("db_core_kernel", "core_point_tests", 1), "union_ms": ("db_group_union_kernel", "union_point_tests", 0),
-             "label_ms": ("db_label_kernel", "label_point_tests", 4)}
-    mean = {nm: float(np.mean([i[nm] for i in infos])) for nm in names}
-    dom = max(mean, key=mean.get)
-    kernel_name, tests_key, out_bytes = names[dom]
-    launches = max(int(info.get("union_launches", 1)), 1) if dom == "union_ms" else 1
-    # SURVEY 8(d) carried over to DBSCAN: 12 B per point whose distance to a query is computed (the query's own
-    # 12 B once per traversal) + what the kernel writes per point (core flag / nothing / label); the union kernel
-    # walks once per packet of 64 groups, not per point: 32 B per node box it looks at + 32 B per group it serves
-    if dom == "union_ms":
-        alg_bytes = (32 * int(info["union_node_tests"]) + 12 * int(info[tests_key]) + 32 * int(info["groups"]) * launches) // launches
-    else:
-        alg_bytes = 12 * int(info[tests_key]) + 12 * n_local + out_bytes * n_local
-    achieved = alg_bytes / (mean[dom] / launches * 1e-3) / 1e9
-    line["roofline"] = {
-        "bound": "hbm",
-        "kernel": kernel_name,
-        "achieved": achieved,
-        "peak": HBM_PEAK_GBS,
-        "unit": "GB/s",
-        "frac": achieved / HBM_PEAK_GBS,
-        "traffic": None,
-        "algorithmic_bytes_per_launch": alg_bytes,
-        "launches_per_step": launches,
-        "kernel_ms": mean[dom] / launches,
-        "timing": "HIP events on the launch stream, recorded inside libowl_mi355x.so around the kernel's launches",
+    kernels = dbscan_rooflines(info, infos, n_local, args.min_pts)
+    # the dominant traversal kernel of the call, by its own HIP-event time (all of them under "kernels")
+    dom = max(kernels, key=lambda nm: kernels[nm]["kernel_ms"] * kernels[nm]["launches_per_step"])
+    line["roofline"] = dict(kernels[dom])
+    line["roofline"].update({
         "groups": int(info.get("groups", 0)),
-        "all_kernels_ms": {"core_flags": mean["core_ms"], "unions": mean["union_ms"], "labels": mean["label_ms"],
-                           "whole_call": float(np.mean([i["solve_ms"] for i in infos]))},
+        "all_kernels_ms": {"core_flags": kernels["db_core_kernel"]["kernel_ms"],
+                           "unions": kernels["db_group_union_kernel"]["kernel_ms"] * kernels["db_group_union_kernel"]["launches_per_step"],
+                           "labels": kernels["db_label_kernel"]["kernel_ms"], "whole_call": float(np.mean([i["solve_ms"] for i in infos]))},
         "point_distance_tests": {"core_flags": int(info["core_point_tests"]), "unions": int(info["union_point_tests"]),
                                  "labels": int(info["label_point_tests"])},
         "node_box_tests": int(info["node_tests"]),
-    }
-    rec, why_not = committed_profile(kernel_name, n_local, args.min_pts)
-    if rec:
-        line["roofline"]["traffic"] = rec["bytes_per_launch"]
-    elif why_not:
-        line["roofline"]["traffic_note"] = why_not
+        "kernels": kernels,
+    })
     return line
+
+
+def dbscan_rooflines(info, infos, n_local, min_pts):
+    """HBM roofline of each traversal kernel of a tknnDbscan call (core flags, group unions, labels), by the kernel's own
+    HIP-event time.  SURVEY 8(d) carried over to DBSCAN: 12 B per point whose distance to a query is computed (the
+    query's own 12 B once per traversal) + what the kernel writes per point (core flag 1 B / label 4 B); the union
+    kernel walks once per packet of 64 groups, not per point: 32 B per node box it looks at + 32 B per group it serves.
+    `traffic` = HBM bytes per launch from the committed PMC record of that kernel (null, with the reason, unless it was
+    taken on these sources); `traffic_over_algorithmic` well above 1 = wasted re-reads / partial-sector writes."""
+    names = {"core_ms": ("db_core_kernel", "core_point_tests", 1), "union_ms": ("db_group_union_kernel", "union_point_tests", 0),
+             "label_ms": ("db_label_kernel", "label_point_tests", 4)}
+    mean = {nm: float(np.mean([i[nm] for i in infos])) for nm in names}
+    out = {}
+    for nm, (kernel_name, tests_key, out_bytes) in names.items():
+        launches = max(int(info.get("union_launches", 1)), 1) if nm == "union_ms" else 1
+        if nm == "union_ms":
+            alg_bytes = (32 * int(info["union_node_tests"]) + 12 * int(info[tests_key]) + 32 * int(info["groups"]) * launches) // launches
+        else:
+            alg_bytes = 12 * int(info[tests_key]) + 12 * n_local + out_bytes * n_local
+        kern_ms = mean[nm] / launches
+        achieved = alg_bytes / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
+        r = {
+            "bound": "hbm",
+            "kernel": kernel_name,
+            "achieved": achieved,
+            "peak": HBM_PEAK_GBS,
+            "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS,
+            "traffic": None,
+            "algorithmic_bytes_per_launch": alg_bytes,
+            "launches_per_step": launches,
+            "kernel_ms": kern_ms,
+            "timing": "HIP events on the launch stream, recorded inside libowl_mi355x.so around the kernel's launches"
+                      + (" (label_ms covers db_label_kernel + db_label_walk_kernel)" if nm == "label_ms" else ""),
+        }
+        rec, why_not = committed_profile(kernel_name, n_local, min_pts)
+        if rec:
+            r["traffic"] = rec["bytes_per_launch"]
+            r["traffic_over_algorithmic"] = rec["bytes_per_launch"] / max(alg_bytes, 1)
+            for kk in ("wave_wait_frac", "FETCH_SIZE_KB_per_launch", "WRITE_SIZE_KB_per_launch"):
+                if kk in rec:
+                    r[kk] = rec[kk]
+        elif why_not:
+            r["traffic_note"] = why_not
+        out[kernel_name] = r
+    return out
+
+
+def dbscan_config3_leg(args, eng, dev, steps=5, warmup=1):
+    """BASELINE configs[2] inside the default run: 10 M Gaussian-mixture points, eps 0.01, minPts 4 through tknnDbscan on
+    the same engine object (new build).  Returns (failed, object for the JSON line)."""
+    from owlraytracing_amd import datasets
+
+    n = N_POINTS
+    eps32 = float(np.float32(DB_EPS))
+    xyz = datasets.gaussian_mixture3d(n, components=64, sigma=0.02, seed=1)
+    build_info = eng.build(torch.from_numpy(xyz).to(dev))
+    for _ in range(warmup):
+        r = eng.dbscan(eps32, DB_MINPTS)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    infos = []
+    for _ in range(steps):
+        r = eng.dbscan(eps32, DB_MINPTS)
+        infos.append(r["info"])
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    info = infos[-1]
+    obj = {
+        "metric": "RT-DBSCAN points/sec (10M Gaussian-mixture pts, eps=0.01, minPts=4)",
+        "value": n * steps / elapsed,
+        "unit": "points/s",
+        "ms_per_step": elapsed / steps * 1e3,
+        "steps": steps,
+        "warmup": warmup,
+        "config": {"workload": "RT-DBSCAN on %d 3-D points of a 64-component Gaussian mixture (sigma 0.02, numpy default_rng(1)), "
+                               "eps=%.6g, minPts=%d; BASELINE.json configs[2]" % (n, eps32, DB_MINPTS)},
+        "clusters": int(info["clusters"]),
+        "groups": int(info.get("groups", 0)),
+        "device_ms_whole_call": float(np.mean([i["solve_ms"] for i in infos])),
+        "build_ms": float(build_info["build_ms"]),
+        "roofline": dbscan_rooflines(info, infos, n, DB_MINPTS),
+        "point_distance_tests": {"core_flags": int(info["core_point_tests"]), "unions": int(info["union_point_tests"]),
+                                 "labels": int(info["label_point_tests"])},
+    }
+    failed = False
+    if not args.no_cpu_baseline:
+        import oracle
+
+        t0 = time.perf_counter()
+        sample = np.random.default_rng(33).choice(n, 2000, replace=False).astype(np.int32)
+        lab, core = r["labels"].cpu().numpy(), r["core"].cpu().numpy()
+        chk = oracle.dbscan_ball_check(xyz, eps32, DB_MINPTS, lab, core, sample)
+        ok = chk["violations"] == 0 and int(lab.max()) + 1 == int(info["clusters"]) and bool(np.all(lab[core.astype(bool)] >= 0))
+        obj["parity_spot_check"] = (
+            "core flags and labels of %d sampled points equal what the CPU spec derives from their recomputed eps-balls "
+            "(oracle/dbscan_oracle.c:dbref_ball_check, %.1fs); all %d points against the threaded CPU spec: "
+            "tests/test_dbscan.py::test_config3_full_size and `bench.py --workload dbscan`" % (len(sample), time.perf_counter() - t0, n)
+            if ok else "MISMATCH (%d of %d sampled points, first %d)" % (chk["violations"], len(sample), chk["first_bad"]))
+        failed = not ok
+        if failed:
+            obj["value"] = None
+    else:
+        obj["parity_spot_check"] = "skipped (--no-cpu-baseline)"
+    return failed, obj
 
 
 if __name__ == "__main__":

@@ -16,9 +16,13 @@ from .loader import (  # noqa: F401
     build,
     dbscan,
     dbscan_auto,
+    dbscan_auto_counts,
+    dbscan_ball_check,
+    dbscan_noise_count,
     dbscan_threaded,
     distance,
     num_threads,
     trueknn,
+    trueknn_rows,
     trueknn_per_query,
 )

@@ -368,3 +368,112 @@ int dbref_dbscan_auto(const float *xyz, int64_t n, float eps0, int min_pts, doub
   }
   return -3;
 }
+
+
+/* ---- count-only growth round and sampled eps-ball check: checks at sizes where the full spec takes too long --------
+ * (BASELINE configs[4]: 50 M 2-D points, eps auto-grown; bench.py's spot check of config 3 inside a run)
+ *
+ * dbref_noise_count_mt: the number of points DBSCAN(eps, minPts) labels -1, without building clusters -- a point is
+ * noise iff it is not core and has no core point within eps (spec above); core flags stop counting at minPts, the
+ * search for a core neighbour stops at the first.  core (n bytes, may be NULL) receives the core flags.
+ * Returns the noise count, or < 0 (bad arguments / out of memory). */
+static int db_has_core_neighbour(const db_grid *g, const float *xyz, const uint8_t *core, int32_t q, float eps) {
+  const float *c = xyz + 3 * (int64_t)q;
+  double reach = (double)eps * 1.0001 + 1e-30;
+  int c0[3], c1[3];
+  for (int a = 0; a < 3; a++) {
+    double slack = reach + 1e-6 * fabs((double)c[a]);
+    c0[a] = db_cell(g, a, (double)c[a] - slack);
+    c1[a] = db_cell(g, a, (double)c[a] + slack);
+  }
+  for (int z = c0[2]; z <= c1[2]; z++)
+    for (int y = c0[1]; y <= c1[1]; y++)
+      for (int x = c0[0]; x <= c1[0]; x++) {
+        int64_t cell = ((int64_t)z * g->dim[1] + y) * g->dim[0] + x;
+        for (int64_t s = g->start[cell]; s < g->start[cell + 1]; s++) {
+          int32_t p = g->items[s];
+          if (core[p] && db_dist(xyz + 3 * (int64_t)p, c) <= eps) return 1;
+        }
+      }
+  return 0;
+}
+
+int64_t dbref_noise_count_mt(const float *xyz, int64_t n, float eps, int min_pts, uint8_t *core_out) {
+  if (!xyz || n <= 0 || !(eps > 0) || min_pts < 1) return -1;
+  db_grid g;
+  if (db_grid_build(&g, xyz, n, (double)eps)) return -2;
+  uint8_t *core = core_out ? core_out : (uint8_t *)malloc((size_t)n);
+  if (!core) return -2;
+#pragma omp parallel for schedule(dynamic, 1024)
+  for (int64_t i = 0; i < n; i++) core[i] = db_count_upto(&g, xyz, (int32_t)i, eps, min_pts) >= min_pts;
+  int64_t noise = 0;
+#pragma omp parallel for schedule(dynamic, 1024) reduction(+ : noise)
+  for (int64_t i = 0; i < n; i++)
+    if (!core[i] && !db_has_core_neighbour(&g, xyz, core, (int32_t)i, eps)) noise++;
+  if (!core_out) free(core);
+  free(g.start);
+  free(g.items);
+  return noise;
+}
+
+/* dbref_ball_check: labels / core flags of a finished clustering (from anywhere: the HIP path) checked on sampled
+ * points by recomputing their eps-balls with the spec's arithmetic:
+ *   core[q] == (|N(q)| >= minPts);
+ *   a core q has a label >= 0 and shares it with every core point of its ball;
+ *   a border q (not core, some core point in its ball) carries the smallest label among those core points;
+ *   a q with no core point in its ball is labelled -1.
+ * Returns the number of sampled points that violate any of these (first_bad: one of them, or -1), < 0 on errors. */
+int64_t dbref_ball_check(const float *xyz, int64_t n, float eps, int min_pts, const int32_t *labels, const uint8_t *core,
+                         const int32_t *sample, int64_t m, int32_t *first_bad) {
+  if (!xyz || !labels || !core || !sample || n <= 0 || m < 0 || !(eps > 0) || min_pts < 1) return -1;
+  db_grid g;
+  if (db_grid_build(&g, xyz, n, (double)eps)) return -2;
+  int64_t bad = 0;
+  int32_t first = -1;
+#pragma omp parallel for schedule(dynamic, 8) reduction(+ : bad)
+  for (int64_t t = 0; t < m; t++) {
+    const int32_t q = sample[t];
+    if (q < 0 || q >= n) {
+      bad++;
+      continue;
+    }
+    const float *c = xyz + 3 * (int64_t)q;
+    double reach = (double)eps * 1.0001 + 1e-30;
+    int c0[3], c1[3];
+    for (int a = 0; a < 3; a++) {
+      double slack = reach + 1e-6 * fabs((double)c[a]);
+      c0[a] = db_cell(&g, a, (double)c[a] - slack);
+      c1[a] = db_cell(&g, a, (double)c[a] + slack);
+    }
+    int64_t count = 0;
+    int32_t best = -1;
+    int differs = 0;
+    for (int z = c0[2]; z <= c1[2]; z++)
+      for (int y = c0[1]; y <= c1[1]; y++)
+        for (int x = c0[0]; x <= c1[0]; x++) {
+          int64_t cell = ((int64_t)z * g.dim[1] + y) * g.dim[0] + x;
+          for (int64_t s = g.start[cell]; s < g.start[cell + 1]; s++) {
+            int32_t p = g.items[s];
+            if (db_dist(xyz + 3 * (int64_t)p, c) > eps) continue;
+            count++;
+            if (!core[p]) continue;
+            if (labels[p] != labels[q]) differs = 1;
+            if (best < 0 || labels[p] < best) best = labels[p];
+          }
+        }
+    int ok = (core[q] != 0) == (count >= min_pts);
+    if (core[q])
+      ok = ok && labels[q] >= 0 && !differs;
+    else
+      ok = ok && labels[q] == (best < 0 ? -1 : best);
+    if (!ok) {
+      bad++;
+#pragma omp critical
+      if (first < 0 || q < first) first = q;
+    }
+  }
+  if (first_bad) *first_bad = first;
+  free(g.start);
+  free(g.items);
+  return bad;
+}

@@ -69,6 +69,13 @@ def _load():
         lib.dbref_dbscan_auto.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_float, ctypes.c_int, ctypes.c_double,
                                           ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                                           ctypes.c_void_p]
+        lib.tkref_trueknn_rows.restype = ctypes.c_int
+        lib.tkref_trueknn_rows.argtypes = lib.tkref_trueknn.argtypes
+        lib.dbref_noise_count_mt.restype = ctypes.c_int64
+        lib.dbref_noise_count_mt.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_float, ctypes.c_int, ctypes.c_void_p]
+        lib.dbref_ball_check.restype = ctypes.c_int64
+        lib.dbref_ball_check.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_float, ctypes.c_int, ctypes.c_void_p,
+                                         ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p]
         assert lib.tkref_sizeof_neigh() == NEIGH_DTYPE.itemsize
         _lib = lib
     return _lib
@@ -129,6 +136,26 @@ def trueknn(xyz, k, start_radius, order=ORDER_ASCENDING, seed=0, query_ids=None,
         "final_radius": float(fr.value),
         "query_seconds": float(lib.tkref_last_query_seconds()),
     }
+
+
+def trueknn_rows(xyz, k, start_radius, query_ids, max_rounds=64):
+    """The restated solve for sampled queries only, rows stored compactly (row t belongs to query_ids[t]): what
+    ``trueknn(..., query_ids=q)`` gives in rows q, without the n*k frameBuffer (24 GB at 10^8 points, k = 10).
+    Returns dict(idx (m,k), dist (m,k), intersections (m,), rounds, final_radius)."""
+    lib = _load()
+    xyz = _points(xyz)
+    n = len(xyz)
+    q = np.ascontiguousarray(query_ids, dtype=np.int32)
+    rows = np.zeros(len(q) * k, dtype=NEIGH_DTYPE)
+    lib.tkref_init_rows(rows.ctypes.data, len(q), k)
+    fr = ctypes.c_float(0)
+    rc = lib.tkref_trueknn_rows(xyz.ctypes.data, n, k, ctypes.c_float(start_radius), ORDER_ASCENDING, 0, q.ctypes.data, len(q),
+                                max_rounds, rows.ctypes.data, ctypes.byref(fr))
+    if rc < 0:
+        raise OracleError({-1: "bad arguments", -2: "out of memory", -3: "max_rounds reached with unfinished queries"}.get(rc, str(rc)))
+    rows = rows.reshape(len(q), k)
+    return {"idx": rows["ind"], "dist": rows["dist"], "intersections": rows["intersections"][:, 0], "rounds": rc,
+            "final_radius": float(fr.value), "query_seconds": float(lib.tkref_last_query_seconds())}
 
 
 def trueknn_per_query(xyz, k, start_radii, max_rounds=64):
@@ -220,3 +247,46 @@ def dbscan_auto(xyz, eps0, min_pts, max_noise=0.05, max_rounds=32):
     return {"labels": labels, "core": core.astype(bool), "clusters": rc, "eps": float(eps.value), "rounds": int(rounds.value),
             "noise": int(noise.value)}
 
+
+
+def dbscan_noise_count(xyz, eps, min_pts, want_core=False):
+    """Number of points DBSCAN(eps, min_pts) labels -1, by the spec, without building clusters (all host cores)."""
+    lib = _load()
+    xyz = _points(xyz)
+    core = np.zeros(len(xyz), np.uint8) if want_core else None
+    rc = int(lib.dbref_noise_count_mt(xyz.ctypes.data, len(xyz), ctypes.c_float(eps), int(min_pts), None if core is None else core.ctypes.data))
+    if rc < 0:
+        raise OracleError("dbref_noise_count_mt: %d" % rc)
+    return (rc, core.astype(bool)) if want_core else rc
+
+
+def dbscan_auto_counts(xyz, eps0, min_pts, max_noise, max_rounds=32):
+    """The growth loop of dbref_dbscan_auto with count-only rounds: dict(rounds, eps, noise) of the round that brings the
+    noise under floor(max_noise * n) -- what the full spec reports, at a cost that allows BASELINE config 5's 50 M points."""
+    xyz = _points(xyz)
+    bound = int(np.floor(float(max_noise) * len(xyz)))
+    eps = np.float32(eps0)
+    for t in range(int(max_rounds)):
+        noise = dbscan_noise_count(xyz, float(eps), min_pts)
+        if noise <= bound:
+            return {"rounds": t + 1, "eps": float(eps), "noise": int(noise)}
+        eps = np.float32(eps * np.float32(2))  # hostCode.cpp:321
+    raise OracleError("max_rounds doublings of eps did not bring the noise under the bound")
+
+
+def dbscan_ball_check(xyz, eps, min_pts, labels, core, sample):
+    """Recompute the eps-balls of the sampled points with the spec's arithmetic and check core flags and labels of a
+    finished clustering on them (dbref_ball_check).  Returns dict(violations, first_bad)."""
+    lib = _load()
+    xyz = _points(xyz)
+    labels = np.ascontiguousarray(labels, dtype=np.int32)
+    core = np.ascontiguousarray(core).astype(np.uint8)
+    sample = np.ascontiguousarray(sample, dtype=np.int32)
+    if len(labels) != len(xyz) or len(core) != len(xyz):
+        raise ValueError("labels / core flags for every point")
+    first = ctypes.c_int32(-1)
+    rc = int(lib.dbref_ball_check(xyz.ctypes.data, len(xyz), ctypes.c_float(eps), int(min_pts), labels.ctypes.data, core.ctypes.data,
+                                  sample.ctypes.data, len(sample), ctypes.byref(first)))
+    if rc < 0:
+        raise OracleError("dbref_ball_check: %d" % rc)
+    return {"violations": rc, "first_bad": int(first.value)}

@@ -127,8 +127,7 @@ float tkref_distance(const float *c_prim, const float *org) {
 }
 
 /* deviceCode.cu:62-138, one call per (query xID, candidate primID) */
-static void tk_intersect(tk_neigh *fb, const float *xyz, int k, int32_t xID, int32_t primID) {
-  tk_neigh *row = fb + (int64_t)xID * k;
+static void tk_intersect(tk_neigh *row /* = &frameBuffer[xID * k] */, const float *xyz, int k, int32_t xID, int32_t primID) {
   row[0].intersections += 1;                                 /* :74 */
   for (int i = 0; i < k; i++)                                /* :77-85 */
     if (row[i].ind == primID) return;
@@ -294,11 +293,15 @@ static int64_t tk_candidates(const tk_grid *g, const float *xyz, const float *q,
  *              -3 max_rounds reached with unfinished queries (the reference would loop forever,
  *              e.g. n <= k)
  */
-int tkref_trueknn(const float *xyz, int64_t n, int k, float start_radius, int order, uint64_t seed,
-                  const int32_t *query_ids, int64_t n_queries, int max_rounds, tk_neigh *fb,
-                  float *final_radius) {
+static int tk_solve(const float *xyz, int64_t n, int k, float start_radius, int order, uint64_t seed,
+                    const int32_t *query_ids, int64_t n_queries, int max_rounds, tk_neigh *fb,
+                    float *final_radius, int compact) {
   if (!xyz || !fb || n <= 0 || k <= 0 || n > INT32_MAX) return -1;
+  if (compact && !query_ids) return -1;
   if (!query_ids) n_queries = n;
+  /* row of the t-th query: at its index in the reference's frameBuffer, or -- compact -- the t-th row of an array that
+   * holds the sampled queries only (100 M points x k = 10 would be 24 GB of frameBuffer for a thousand sampled rows) */
+#define TK_ROW(t, xID) (fb + (compact ? (int64_t)(t) : (int64_t)(xID)) * k)
   float radius = start_radius;
   int rounds = 0;
   g_query_seconds = 0.0;
@@ -316,7 +319,8 @@ int tkref_trueknn(const float *xyz, int64_t n, int k, float start_radius, int or
 #pragma omp for schedule(dynamic, 256)
       for (int64_t t = 0; t < n_queries; t++) {
         int32_t xID = query_ids ? query_ids[t] : (int32_t)t;
-        if (!(fb[(int64_t)xID * k].numNeighbors > 0)) continue; /* deviceCode.cu:148 */
+        tk_neigh *row = TK_ROW(t, xID);
+        if (!(row[0].numNeighbors > 0)) continue; /* deviceCode.cu:148 */
         int64_t m = tk_candidates(&g, xyz, xyz + 3 * (int64_t)xID, radius, order,
                                   seed ^ tk_mix((uint64_t)xID * 1315423911ull + (uint64_t)rounds),
                                   &buf, &cap);
@@ -324,7 +328,7 @@ int tkref_trueknn(const float *xyz, int64_t n, int k, float start_radius, int or
           failed = 1;
           continue;
         }
-        for (int64_t j = 0; j < m; j++) tk_intersect(fb, xyz, k, xID, buf[j]);
+        for (int64_t j = 0; j < m; j++) tk_intersect(row, xyz, k, xID, buf[j]);
       }
       free(buf);
     }
@@ -334,7 +338,7 @@ int tkref_trueknn(const float *xyz, int64_t n, int k, float start_radius, int or
     int again = 0; /* hostCode.cpp:310-330 */
     for (int64_t t = 0; t < n_queries; t++) {
       int32_t j = query_ids ? query_ids[t] : (int32_t)t;
-      if (fb[(int64_t)j * k].numNeighbors > 0) {
+      if (TK_ROW(t, j)[0].numNeighbors > 0) {
         again = 1;
         radius *= 2;
         break;
@@ -344,6 +348,22 @@ int tkref_trueknn(const float *xyz, int64_t n, int k, float start_radius, int or
   }
   if (final_radius) *final_radius = radius;
   return rounds;
+#undef TK_ROW
+}
+
+int tkref_trueknn(const float *xyz, int64_t n, int k, float start_radius, int order, uint64_t seed,
+                  const int32_t *query_ids, int64_t n_queries, int max_rounds, tk_neigh *fb,
+                  float *final_radius) {
+  return tk_solve(xyz, n, k, start_radius, order, seed, query_ids, n_queries, max_rounds, fb, final_radius, 0);
+}
+
+/* The same solve for sampled queries only, rows stored compactly: `rows` holds n_queries * k records (initialised with
+ * tkref_init_rows(rows, n_queries, k)), row t belongs to query_ids[t].  For checks at sizes where the reference's
+ * n * k frameBuffer would not fit the checker's host (BASELINE config 4: 10^8 points). */
+int tkref_trueknn_rows(const float *xyz, int64_t n, int k, float start_radius, int order, uint64_t seed,
+                       const int32_t *query_ids, int64_t n_queries, int max_rounds, tk_neigh *rows,
+                       float *final_radius) {
+  return tk_solve(xyz, n, k, start_radius, order, seed, query_ids, n_queries, max_rounds, rows, final_radius, 1);
 }
 
 /*

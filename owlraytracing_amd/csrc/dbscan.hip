@@ -96,6 +96,9 @@ __device__ __forceinline__ void box_dist2(const LbvhNode &nd, const LbvhPoint &q
   far2 = ax * ax + ay * ay + az * az;
   near2 = bx * bx + by * by + bz * bz;
 }
+// per-axis reach of a union pass's box prefilter from the pass's bound on the squared distance of nearest faces: at
+// least its square root (sqrtf is correctly rounded; two parts in 10^6 cover that rounding and the squares' in near2)
+inline float db_reach_of(float near_hi2) { return sqrtf(near_hi2) * 1.000002f; }
 __device__ __forceinline__ bool node_is_tight(const LbvhNode &nd, float eps_in2) {
   const float ex = nd.hi[0] - nd.lo[0], ey = nd.hi[1] - nd.lo[1], ez = nd.hi[2] - nd.lo[2];
   return ex * ex + ey * ey + ez * ez <= eps_in2;  // NaN boxes (none: fit ignores NaN points) would be "not tight"
@@ -1098,13 +1101,18 @@ void Engine::dbscan(float eps, int min_pts, int32_t *d_labels, uint8_t *d_core, 
     hipLaunchKernelGGL(db_group_kernel, dim3(blocks), dim3(kDbBlock), 0, s, a, group_at);
     OWLMI_HIP(hipcub::DeviceSelect::If(scan_tmp, scan_bytes, group_at, groups, n_groups, (int)n, DbIsGroup(), s));
     // persistent lanes: as many workgroups as the device holds at once (the list's length is known on the device only)
-    static const int resident = [] {
-      int per_cu = 0, dev = 0;
+    // (per engine: the CU count and the occupancy are those of THIS engine's device)
+    if (db_union_resident_ == 0) {
+      int per_cu = 0;
       hipDeviceProp_t prop;
-      if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 256 * 4;
-      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)db_group_union_kernel, kDbUnionBlock, 0) != hipSuccess) per_cu = 4;
-      return prop.multiProcessorCount * std::max(1, per_cu);
-    }();
+      if (hipGetDeviceProperties(&prop, device_) != hipSuccess) {
+        db_union_resident_ = 256 * 4;
+      } else {
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)db_group_union_kernel, kDbUnionBlock, 0) != hipSuccess) per_cu = 4;
+        db_union_resident_ = prop.multiProcessorCount * std::max(1, per_cu);
+      }
+    }
+    const int resident = db_union_resident_;
     unsigned grid = blocks < (unsigned)resident ? blocks : (unsigned)resident;
     if (getenv("TKNN_DB_GRID")) grid = std::max(1, std::min((int)grid, atoi(getenv("TKNN_DB_GRID"))));  // measurements
     // Two passes: first the pairs of groups that (nearly) touch -- in a dense region their probes hit at once, and when the
@@ -1112,9 +1120,13 @@ void Engine::dbscan(float eps, int min_pts, int32_t *d_labels, uint8_t *d_core, 
     // set already and cost a parent read instead of a probe that would have to look at many point pairs to find one close
     // enough (or none).  One pass settles everything as soon as it is met: 4 times the point tests, 14 ms instead of 4.
     const float split = getenv("TKNN_DB_SPLIT") ? (float)atof(getenv("TKNN_DB_SPLIT")) : 0.25f;
+    // ONE number bounds both passes: pass 1 takes near2 <= near_hi2, pass 2 near2 > that same value, and the per-axis
+    // reach of a pass's box prefilter is derived from its near_hi2 (>= its square root, DbArgs), so that no pair whose
+    // faces are between split * eps_wide and sqrt(near_hi2) apart along one axis falls between the passes
+    // (reach = split * eps (1 + 1e-6) against near2 <= split^2 eps^2 (1 + 1e-5) left a 34-ulp window).
     a.near_lo2 = -1.f;
     a.near_hi2 = split * split * a.eps_out2;
-    a.reach = split * a.eps_wide;
+    a.reach = db_reach_of(a.near_hi2);
     OWLMI_HIP(hipEventRecord(ev_d_, s));
     if (split < 1.f) {
       union_launches = 2;
@@ -1123,7 +1135,7 @@ void Engine::dbscan(float eps, int min_pts, int32_t *d_labels, uint8_t *d_core, 
       a.near_lo2 = a.near_hi2;
     }
     a.near_hi2 = a.eps_out2;
-    a.reach = a.eps_wide;
+    a.reach = db_reach_of(a.near_hi2);
     hipLaunchKernelGGL(db_group_union_kernel, dim3(grid), dim3(kDbUnionBlock), 0, s, a, groups, n_groups, n_groups + 1, n_groups + 9);
   }
   OWLMI_HIP(hipEventRecord(ev_e_, s));

@@ -275,12 +275,15 @@ struct Buffer : Object {
   void *ptr = nullptr;
   // Managed buffers in "mirror" form (the default, see managed_policy): `ptr` is DEVICE memory -- what BUFPTR
   // variables hand to device code -- and `mirror` a pinned host copy -- what owlBufferGetPointer hands to host code.
-  // Both sides see one coherent buffer at the API's synchronisation points: the mirror is refreshed by one bulk
-  // copy when the host asks for the pointer after a launch, and written back before the next launch.
+  // Both sides see one coherent buffer at the API's synchronisation points (owlLaunch2D's return, owlLaunchSync,
+  // owlBufferGetPointer), like managed memory after a device synchronisation: once the host has been given the
+  // pointer it may keep it, so from then on every launch is preceded by a mirror -> device copy and every
+  // synchronisation point followed by a device -> mirror copy (refresh_mirrors) -- a host program that fetches the
+  // pointer once and re-reads it after later launches sees their results (tests/test_owl_api.py).
   void *mirror = nullptr;
   bool mirrored = false;      // this buffer uses the mirror form
   bool device_newer = false;  // a launch ran since the mirror was last refreshed
-  bool host_may_have_written = false;  // the host has held the mirror's pointer since the last write-back
+  bool handed_out = false;    // the host holds the mirror's pointer (it may read and write it between synchronisation points)
   size_t elem() const { return size_of_type(type); }
   size_t bytes() const { return elem() * count; }
   void release() {
@@ -474,7 +477,7 @@ void Buffer::allocate(const void *init) {
       OWL_HIP(hipMemcpy(ptr, mirror, n, hipMemcpyHostToDevice));
     }
     device_newer = false;
-    host_may_have_written = false;
+    handed_out = false;
   } else if (bkind == BufferKind::Managed) {
     // one address valid on host and device (owlBufferGetPointer is read on the host by
     // samples/s01-trueknn/hostCode.cpp:294-313)
@@ -746,14 +749,29 @@ const void *Buffer::host_pointer() {
     OWL_HIP(hipMemcpy(mirror, ptr, bytes() ? bytes() : 16, hipMemcpyDeviceToHost));
     device_newer = false;
   }
-  host_may_have_written = true;  // the caller holds a writable pointer from now on
+  handed_out = true;  // the caller holds a writable pointer from now on
   return mirror;
 }
 
+// Before a launch: what the host may have written through the pointer it holds.  Not while the device side is newer
+// than the mirror (an asynchronous launch has run and no synchronisation point has passed): the host has had no
+// legal look at the buffer since, and the copy would overwrite that launch's results.
 void Buffer::write_back(hipStream_t s) {
-  if (!mirrored || !host_may_have_written || !ptr) return;
+  if (!mirrored || !handed_out || device_newer || !ptr) return;
   OWL_HIP(hipMemcpyAsync(ptr, mirror, bytes() ? bytes() : 16, hipMemcpyHostToDevice, s));
-  host_may_have_written = false;
+}
+
+// At a synchronisation point: every mirror whose pointer the host holds shows what the launches so far have written.
+static void refresh_mirrors(Context &c) {
+  bool synced = false;
+  for (auto &wb : c.buffers)
+    if (auto b = wb.lock())
+      if (b->mirrored && b->handed_out && b->device_newer && b->ptr) {
+        if (!synced) OWL_HIP(hipDeviceSynchronize());  // launches of every OWLParams stream that may still write the buffer
+        synced = true;
+        OWL_HIP(hipMemcpy(b->mirror, b->ptr, b->bytes() ? b->bytes() : 16, hipMemcpyDeviceToHost));
+        b->device_newer = false;
+      }
 }
 
 void launch(RayGen &rg, int dx, int dy, Params *lp, bool sync) {
@@ -807,7 +825,10 @@ void launch(RayGen &rg, int dx, int dy, Params *lp, bool sync) {
         if (b->bkind == BufferKind::Managed && b->ptr && !b->mirrored)
           if (hipMemPrefetchAsync(b->ptr, b->bytes() ? b->bytes() : 16, hipCpuDeviceId, s) != hipSuccess) (void)hipGetLastError();
   }
-  if (sync) OWL_HIP(hipStreamSynchronize(s));
+  if (sync) {
+    OWL_HIP(hipStreamSynchronize(s));
+    refresh_mirrors(c);
+  }
 }
 
 [[noreturn]] void unsupported(const char *what) {
@@ -1132,7 +1153,8 @@ OWL_API void owlTrianglesSetVertices(OWLGeom, OWLBuffer, size_t, size_t, size_t)
 OWL_API void owlTrianglesSetMotionVertices(OWLGeom, size_t, OWLBuffer *, size_t, size_t, size_t) { unsupported("triangle meshes"); }
 OWL_API void owlTrianglesSetIndices(OWLGeom, OWLBuffer, size_t, size_t, size_t) { unsupported("triangle meshes"); }
 
-OWL_API void owlRayGenLaunch2D(OWLRayGen rayGen, int dx, int dy) { launch(*get<RayGen>(rayGen, Kind::RayGen), dx, dy, nullptr, false); }
+// synchronous like the reference's (RayGen.cpp:134-138: launchAsync on the dummy launch params, then their sync)
+OWL_API void owlRayGenLaunch2D(OWLRayGen rayGen, int dx, int dy) { launch(*get<RayGen>(rayGen, Kind::RayGen), dx, dy, nullptr, true); }
 OWL_API void owlLaunch2D(OWLRayGen rayGen, int dx, int dy, OWLParams params) {
   auto lp = get<Params>(params, Kind::Params);
   launch(*get<RayGen>(rayGen, Kind::RayGen), dx, dy, lp.get(), true);
@@ -1142,7 +1164,11 @@ OWL_API void owlAsyncLaunch2D(OWLRayGen rayGen, int dx, int dy, OWLParams params
   launch(*get<RayGen>(rayGen, Kind::RayGen), dx, dy, lp.get(), false);
 }
 OWL_API CUstream owlParamsGetCudaStream(OWLParams params, int) { return get<Params>(params, Kind::Params)->stream; }
-OWL_API void owlLaunchSync(OWLParams params) { OWL_HIP(hipStreamSynchronize(get<Params>(params, Kind::Params)->stream)); }
+OWL_API void owlLaunchSync(OWLParams params) {
+  auto lp = get<Params>(params, Kind::Params);
+  OWL_HIP(hipStreamSynchronize(lp->stream));
+  refresh_mirrors(*lp->ctx);
+}
 
 // ---- releases, variable handles ------------------------------------------------------------------
 static void release_handle(const void *h) {

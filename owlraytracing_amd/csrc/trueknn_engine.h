@@ -107,6 +107,7 @@ class Engine {
   unsigned long long *counters_ = nullptr, *h_counters_ = nullptr;
   void *wave_ws_ = nullptr;
   size_t wave_ws_bytes_ = 0;
+  int db_union_resident_ = 0;     // workgroups of db_group_union_kernel this engine's device holds at once (0: not asked yet)
   bool db_force_point_ = false;   // dbscan(): per-point unions (the fallback when a packet walk of the group unions ran out of stack)
   bool wave_force_redo_ = false;  // TKNN_WAVE_FORCE_REDO (tests): treat every wave-kernel solve as if its LDS stack had overflowed
   int wave_leaf_max_ = 16;  // subtrees of at most this many points are streamed as one range (TKNN_LEAF_MAX)

@@ -350,16 +350,20 @@ class ShardedTrueKNN:
                 worker = threading.Thread(target=run_interior, name="tknn-interior")
                 t_int = time.perf_counter()
                 worker.start()
-            got = comm.exchange_rows(blocks, 4, torch.float32, dev)
-            got[comm.rank] = got[comm.rank][:0]
-            halo = torch.cat(got, dim=0)
-            t = lap("exchange", t)
-            exchanges += 1
-            halo_points = len(halo)
-            self.engine.set_halo(halo[:, :3].contiguous(), halo[:, 3].contiguous().view(torch.int32))
-            t = lap("halo_build", t)
+            try:
+                got = comm.exchange_rows(blocks, 4, torch.float32, dev)
+                got[comm.rank] = got[comm.rank][:0]
+                halo = torch.cat(got, dim=0)
+                t = lap("exchange", t)
+                exchanges += 1
+                halo_points = len(halo)
+                self.engine.set_halo(halo[:, :3].contiguous(), halo[:, 3].contiguous().view(torch.int32))
+                t = lap("halo_build", t)
+            finally:
+                # the interior solve uses self.engine on its own stream: never unwind past it
+                if worker is not None:
+                    worker.join()
             if worker is not None:
-                worker.join()
                 if "error" in interior:
                     raise interior["error"]
                 phase["interior_solve_overlapped"] = phase.get("interior_solve_overlapped", 0.0) + (time.perf_counter() - t_int) * 1e3
@@ -464,7 +468,7 @@ class ShardedTrueKNN:
         known = core & (lab != big)
         core_label = torch.where(known, number, torch.full_like(number, -1)).int()
         labels = self.db_engine.dbscan_assign(eps32, core_label)
-        info = {"clusters": int(len(everyone)), "rounds": rounds, "halo_points": int(len(halo))}
+        info = {"clusters": int(len(everyone)), "rounds": rounds, "label_rounds": rounds, "halo_points": int(len(halo))}
         return {"labels": labels[:m].to(dev), "core": core[:m], "info": info}
 
     def _db_setup(self, eps32, reuse=False):
@@ -508,7 +512,8 @@ class ShardedTrueKNN:
             comm.all_reduce(noise, dist.ReduceOp.SUM)
             if int(noise.item()) <= bound:
                 r = self.dbscan(float(eps), min_pts, _reuse_setup=True)  # (same eps: the round's halo and tree)
-                r["info"].update({"rounds": t + 1, "eps": float(eps), "noise": int(noise.item())})
+                # "rounds" = growth rounds, as in tknnDbscanAutoInfo; the label propagation's rounds stay in "label_rounds"
+                r["info"].update({"rounds": t + 1, "eps_rounds": t + 1, "eps": float(eps), "noise": int(noise.item())})
                 return r
             eps = np.float32(eps * np.float32(2))
         raise _lib.TknnError(-4, "max_rounds doublings of eps did not bring the noise under the bound")

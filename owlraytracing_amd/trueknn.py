@@ -121,23 +121,26 @@ class TrueKNN:
     supports_phases = True  # solve(phase=1 | 2): interior / boundary queries of a tile (tknnSolveOptions.phase)
 
     def solve(self, k, start_radius, kernel=_lib.KERNEL_AUTO, max_rounds=64, want_fb=False,
-              out=None, want_levels=False, allow_unfinished=False, phase=0, stream=None, start_radii=None):
+              out=None, want_levels=False, allow_unfinished=False, phase=0, stream=None, start_radii=None, fb_only=False):
         """Returns dict(idx (n,k) int32, dist (n,k) f32, intersections (n,) int64[, fb (n*k*24,) uint8])
         as CUDA tensors plus ``info``.  ``out`` may carry preallocated tensors of those names.
         ``phase`` 1 / 2: only the interior / boundary queries marked by the last ``halo_select`` (sharded use);
         ``stream``: a torch.cuda.Stream to launch on instead of the current one (a phase-1 solve runs on a
         stream and host thread of its own beside the halo exchange).
         ``start_radii``: (n,) float32, a start radius per query (row) instead of ``start_radius`` for all -- the opt-in
-        per-query radius schedule (tknnSolveOptions.d_start_radii)."""
+        per-query radius schedule (tknnSolveOptions.d_start_radii).
+        ``fb_only``: only the reference's frameBuffer records are written (d_idx = d_dist = d_intersections = NULL), the
+        way the reference's own host code receives its results."""
         torch = self._torch
         n = self.n
         out = dict(out or {})
         with torch.cuda.device(self.device):
             if n > 0 and k > 0:
-                out.setdefault("idx", torch.empty((n, k), dtype=torch.int32, device=self.device))
-                out.setdefault("dist", torch.empty((n, k), dtype=torch.float32, device=self.device))
-                out.setdefault("intersections", torch.empty((n,), dtype=torch.int64, device=self.device))
-                if want_fb:
+                if not fb_only:
+                    out.setdefault("idx", torch.empty((n, k), dtype=torch.int32, device=self.device))
+                    out.setdefault("dist", torch.empty((n, k), dtype=torch.float32, device=self.device))
+                    out.setdefault("intersections", torch.empty((n,), dtype=torch.int64, device=self.device))
+                if want_fb or fb_only:
                     out.setdefault("fb", torch.empty((n * k * NEIGH_BYTES,), dtype=torch.uint8, device=self.device))
                 if want_levels or allow_unfinished:
                     out.setdefault("levels", torch.empty((n,), dtype=torch.int32, device=self.device))

@@ -2,7 +2,7 @@
 // OWL C-ABI (include/owl/owl_host.h).  Written for the tests (not the reference's hostCode.cpp):
 // inputs and outputs are raw binary files so that pytest can compare with the CPU checker.
 //
-//   owl_host_driver knn    <module.hsaco> <points.f32> <n> <k> <radius> <out_fb.bin>
+//   owl_host_driver knn    <module.hsaco> <points.f32> <n> <k> <radius> <out_fb.bin> [held]
 //       TrueKNN through owl*: the round loop of samples/s01-trueknn/hostCode.cpp:285-340 driven
 //       over a device-program module that exports the reference's program names ("Spheres",
 //       "rayGen") and struct layouts (GeomTypes.h).  Writes the n*k 24-byte Neigh records and
@@ -125,11 +125,22 @@ static int run_knn(int argc, char **argv) {
   owlBuildPrograms(ctx);
   owlBuildPipeline(ctx);
   owlBuildSBT(ctx);
+  // "held" (9th argument): the pointer of the managed frameBuffer is fetched ONCE, before the first launch, and re-read
+  // after every launch -- legal for managed memory in the reference API (one address, coherent after a synchronising
+  // launch); a marker the host writes through it between two launches must reach the device and come back.
+  const bool held = argc > 8 && !std::strcmp(argv[8], "held");
+  NeighRec *held_rows = held ? (NeighRec *)owlBufferGetPointer(fb, 0) : nullptr;
+  bool marker_ok = true;
   int rounds = 0;
   for (;;) {
     rounds++;
+    if (held && rounds == 2 && k > 1) held_rows[1].intersections = 0x5eed5eedLL;  // (slot 1's counter: device code never touches it)
     owlLaunch2D(rg, (int)n, 1, lp);
-    const NeighRec *rows = (const NeighRec *)owlBufferGetPointer(fb, 0);
+    if (held && rounds == 2 && k > 1) {
+      marker_ok = held_rows[1].intersections == 0x5eed5eedLL;
+      held_rows[1].intersections = 0;
+    }
+    const NeighRec *rows = held ? held_rows : (const NeighRec *)owlBufferGetPointer(fb, 0);
     bool again = false;
     for (size_t j = 0; j < n; j++)
       if (rows[j * k].numNeighbors > 0) {
@@ -143,8 +154,8 @@ static int run_knn(int argc, char **argv) {
     owlGroupRefitAccel(blas);
     owlGroupRefitAccel(world);
   }
-  write_file(argv[7], owlBufferGetPointer(fb, 0), init.size() * sizeof(NeighRec));
-  std::printf("rounds=%d final_radius=%.9g\n", rounds, radius);
+  write_file(argv[7], held ? (const void *)held_rows : owlBufferGetPointer(fb, 0), init.size() * sizeof(NeighRec));
+  std::printf("rounds=%d final_radius=%.9g%s\n", rounds, radius, held ? (marker_ok ? " held_marker=ok" : " held_marker=LOST") : "");
   owlContextDestroy(ctx);
   return 0;
 }

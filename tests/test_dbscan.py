@@ -1,6 +1,8 @@
 """RT-DBSCAN: the spec of oracle/dbscan_oracle.c against sklearn, and
 the HIP path against both.  The reference has no source for this, so parity is unpinned; sklearn's
 labelling is the external anchor."""
+import os
+
 import numpy as np
 import pytest
 
@@ -135,6 +137,59 @@ def test_group_unions_equal_point_unions(monkeypatch):
         assert np.array_equal(by_point["labels"].cpu().numpy(), ref["labels"]), name
         assert by_group["info"]["clusters"] == ref["clusters"] == by_point["info"]["clusters"], name
         assert by_group["info"]["node_tests"] < by_point["info"]["node_tests"], name
+    eng.close()
+
+
+def _gap_quadruples(eps, split=0.25, rel=(-1e-5, 1e-5), steps=81):
+    """Pairs of two-point groups facing each other along ONE axis across a gap of split * eps * (1 + d), d swept over
+    `rel` -- the seam between the two passes of the group-union kernel (first pass: nearest faces within split * eps,
+    second pass: the rest).  The facing points sit at 0 and at the gap on that axis, so fp32 resolves steps of 1e-7 of the
+    gap.  Every quadruple is one cluster (the gap is a quarter of eps); quadruples are several eps apart."""
+    eps = np.float32(eps)
+    spacing = np.float32(3.0 + 6.0 * float(eps))
+    width = np.float32(0.9) * eps  # a group's box: diagonal 0.9 eps < eps -> a tight node
+    rows = []
+    for j, d in enumerate(np.linspace(rel[0], rel[1], steps)):
+        for axis in range(3):
+            gap = np.float32(float(split) * float(eps) * (1.0 + d))
+            base = spacing * np.float32([1 + j % 9, 1 + j // 9, 1 + j // 9])
+            base[(axis + 1) % 3] = spacing * np.float32(1 + j % 9)
+            base[(axis + 2) % 3] = spacing * np.float32(1 + j // 9)
+            for t in (-width, np.float32(0), gap, gap + width):
+                p = base.copy()
+                p[axis] = t
+                rows.append(p)
+    return np.ascontiguousarray(np.stack(rows), dtype=np.float32)
+
+
+def test_gap_quadruples_are_single_clusters_in_the_spec():
+    for eps in (0.01, 1.0, 0.37, 0.0008):
+        xyz = _gap_quadruples(eps)
+        r = oracle.dbscan(xyz, float(np.float32(eps)), 2)
+        assert r["clusters"] == len(xyz) // 4, eps
+        assert np.array_equal(r["labels"], np.arange(len(xyz)) // 4), eps
+
+
+@pytest.mark.gpu
+def test_union_passes_leave_no_gap_between_them():
+    """pass 1 of the group unions prefiltered with a per-axis reach of split * eps (1 + 1e-6) but accepted
+    squared face distances up to split^2 eps^2 (1 + 1e-5), and pass 2 started above that bound: two groups whose faces were
+    between the two numbers apart along one axis were united by neither pass.  The advisor's four points, and sweeps of such
+    gaps along each axis at several eps (groups of two points, 0.9 eps wide, so each is a tight node)."""
+    from owlraytracing_amd.trueknn import TrueKNN
+    eng = TrueKNN()
+    four = np.zeros((4, 3), np.float32)
+    four[:, 0] = np.float32([0.0, 0.9, 1.1500007, 2.05])
+    cases = [("advisor_four_points", four, 1.0, 2)]
+    for eps in (0.01, 1.0, 0.37, 0.0008):
+        cases.append(("gaps_eps_%g" % eps, _gap_quadruples(eps), eps, 2))
+    for name, xyz, eps, min_pts in cases:
+        eps = float(np.float32(eps))
+        ref = oracle.dbscan(xyz, eps, min_pts)
+        eng.build(xyz)
+        got = eng.dbscan(eps, min_pts)
+        assert got["info"]["clusters"] == ref["clusters"], name
+        assert np.array_equal(got["labels"].cpu().numpy(), ref["labels"]), name
     eng.close()
 
 
@@ -355,3 +410,101 @@ def test_hip_dbscan_auto_equals_the_spec():
         with pytest.raises(_lib.TknnError):
             eng.dbscan_auto(*bad)
     eng.close()
+
+
+def test_count_only_rounds_and_ball_check_equal_the_full_spec():
+    """The cheap checkers used at sizes the full spec cannot be run at (BASELINE config 5's 50 M points; bench.py's spot
+    check of config 3): the count-only growth loop reports the full loop's (rounds, eps, noise) and core flags; the
+    sampled eps-ball check accepts the spec's own labelling and notices a wrong label, a wrong core flag, a border point
+    given to another cluster and a noise point given a cluster."""
+    xyz = datasets.pad_to_3d(datasets.taxi_like2d(8000, components=12, seed=5))
+    eps0, min_pts = float(np.float32(0.0004)), 4
+    for max_noise in (0.5, 0.1, 0.01):
+        full, counts = oracle.dbscan_auto(xyz, eps0, min_pts, max_noise), oracle.dbscan_auto_counts(xyz, eps0, min_pts, max_noise)
+        assert (full["rounds"], full["eps"], full["noise"]) == (counts["rounds"], counts["eps"], counts["noise"])
+    for pts, eps, m in ((xyz, 0.004, 6), (datasets.gaussian_mixture3d(6000, components=5, sigma=0.03, seed=9), 0.02, 4)):
+        eps = float(np.float32(eps))
+        ref = oracle.dbscan(pts, eps, m)
+        noise, core = oracle.dbscan_noise_count(pts, eps, m, want_core=True)
+        assert noise == int((ref["labels"] < 0).sum()) and np.array_equal(core, ref["core"].astype(bool))
+        every = np.arange(len(pts), dtype=np.int32)
+        assert oracle.dbscan_ball_check(pts, eps, m, ref["labels"], ref["core"], every) == {"violations": 0, "first_bad": -1}
+        lab, cr = ref["labels"].copy(), ref["core"].astype(bool).copy()
+        border = np.flatnonzero(~cr & (lab >= 0))
+        noise_pts = np.flatnonzero(lab < 0)
+        core_pts = np.flatnonzero(cr)
+        # one defect at a time, checked on the defective point itself
+        for q, change in ((core_pts[3], "label"), (core_pts[7], "core"), (border[0] if len(border) else None, "label"),
+                          (noise_pts[0] if len(noise_pts) else None, "label")):
+            if q is None:
+                continue
+            l2, c2 = lab.copy(), cr.copy()
+            if change == "label":
+                l2[q] = l2[q] + 1 if l2[q] >= 0 else 0
+            else:
+                c2[q] = not c2[q]
+            r = oracle.dbscan_ball_check(pts, eps, m, l2, c2, np.int32([q]))
+            assert r["violations"] == 1 and r["first_bad"] == q, (q, change)
+
+
+@pytest.mark.gpu
+def test_config5_set_full_size_auto_eps():
+    """BASELINE config 5's point set on ONE GPU -- 50 M heavy-tailed 2-D points (5 % exact duplicates), minPts 4, eps
+    auto-grown from 5e-5 until at most 5 % of the points are noise (the run README / DESIGN quote a time for):
+      * rounds, final eps and noise count equal the count-only CPU spec's growth loop (oracle.dbscan_auto_counts,
+        all host cores), and the core flags of all 5e7 points equal that spec's at the final eps;
+      * labels: noise count = number of -1 labels, clusters = max label + 1, core points are never noise, and the
+        eps-balls of 2 500 sampled points recomputed by the CPU spec (oracle.dbscan_ball_check): core <=> |N(p)| >= minPts,
+        a core point shares its label with every core point in its ball, a border point carries the smallest label among
+        them, a point with none is noise."""
+    import torch
+
+    from owlraytracing_amd.trueknn import TrueKNN
+    n = 50_000_000
+    xyz = datasets.pad_to_3d(datasets.taxi_like2d(n, components=256, seed=2))
+    eps0, min_pts, max_noise = float(np.float32(0.00005)), 4, 0.05
+    eng = TrueKNN()
+    eng.build(torch.from_numpy(xyz).cuda())
+    got = eng.dbscan_auto(eps0, min_pts, max_noise)
+    info = got["info"]
+    lab, core = got["labels"].cpu().numpy(), got["core"].cpu().numpy().astype(bool)
+    eng.close()
+    torch.cuda.empty_cache()
+    assert info["noise"] == int((lab < 0).sum()) <= int(np.floor(max_noise * n))
+    assert info["clusters"] == int(lab.max()) + 1 and np.all(lab[core] >= 0)
+    want = oracle.dbscan_auto_counts(xyz, eps0, min_pts, max_noise)
+    assert (info["rounds"], info["eps"], info["noise"]) == (want["rounds"], want["eps"], want["noise"])
+    noise, cpu_core = oracle.dbscan_noise_count(xyz, info["eps"], min_pts, want_core=True)
+    assert noise == info["noise"] and np.array_equal(core, cpu_core)
+    sample = np.random.default_rng(55).choice(n, 2500, replace=False).astype(np.int32)
+    assert oracle.dbscan_ball_check(xyz, info["eps"], min_pts, lab, core, sample) == {"violations": 0, "first_bad": -1}
+    print("config-5 set on one GPU: %d rounds, eps %.6g, noise %d, %d clusters; growth rounds %.1f ms + clustering %.1f ms" % (
+        info["rounds"], info["eps"], info["noise"], info["clusters"], info["probe_ms"], info["solve_ms"]))
+
+
+@pytest.mark.gpu
+def test_rarely_taken_union_paths():
+    """The group-union kernel's depth-first popping (a packet walk whose LDS stack is nearly full pops one reference at a
+    time) and the host's fallback to per-point unions after a stack overflow never happen on ordinary inputs with the
+    shipped stack of 512 references.  libowl_mi355x_diag.so is built with a stack of 320 (depth-first on these sets) and
+    reports an overflow on demand (TKNN_DB_DIAG=16): scripts/db_fallback_check.py compares three sets with the CPU spec."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib = os.path.join(root, "owlraytracing_amd", "libowl_mi355x_diag.so")
+    if not os.path.exists(lib):
+        pytest.fail("libowl_mi355x_diag.so is not built: __graft_entry__.build() makes it (make -C owlraytracing_amd/csrc DIAG=1)")
+    for diag, expect in ((None, "groups"), ("16", "groups 0 ")):
+        env = dict(os.environ, OWL_MI355X_LIB=lib)
+        env.pop("TKNN_DB_DIAG", None)
+        if diag:
+            env["TKNN_DB_DIAG"] = diag
+        r = subprocess.run([sys.executable, os.path.join(root, "scripts", "db_fallback_check.py")], capture_output=True, text=True, timeout=600, env=env)
+        assert r.returncode == 0, r.stdout + r.stderr
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("ok ")]
+        assert len(lines) == 3, r.stdout
+        if diag:  # the fallback ran: per-point unions report no groups and one union launch
+            assert all(expect in ln and ln.rstrip().endswith("union launches 1") for ln in lines), r.stdout
+        else:
+            assert all("union launches 2" in ln for ln in lines), r.stdout

@@ -160,6 +160,41 @@ def test_reference_device_programs_through_owl_api_match_the_checker(tmp_path):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("policy", ["mirror", "managed"])
+def test_managed_buffer_pointer_held_across_launches(tmp_path, policy):
+    """owlManagedMemoryBufferCreate gives ONE address that stays coherent after a synchronising launch
+    (owl/Buffer.cpp:307-360, cudaMallocManaged).  A host program that fetches owlBufferGetPointer once and re-reads it
+    after later launches must see their results, and what it writes through the pointer between two launches must
+    reach the device -- in the default mirror form as with plain managed memory (OWL_MANAGED_POLICY=0)."""
+    if not os.path.exists(REF_HSACO):
+        pytest.skip("oracle/_ref/deviceCode.hsaco not built (no reference tree at build time)")
+    _need_driver()
+    import oracle
+    from owlraytracing_amd import datasets
+    n, k = 15000, 6
+    pts = datasets.uniform3d(n, seed=17)
+    r0 = float(np.float32(datasets.start_radius(n, k)))
+    (tmp_path / "pts.f32").write_bytes(pts.tobytes())
+    out = tmp_path / "fb.bin"
+    env = dict(os.environ)
+    env.pop("OWL_MANAGED_POLICY", None)
+    if policy == "managed":
+        env["OWL_MANAGED_POLICY"] = "0"
+    r = subprocess.run([DRIVER, "knn", REF_HSACO, str(tmp_path / "pts.f32"), str(n), str(k), repr(r0), str(out), "held"],
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stdout + r.stderr
+    ref = oracle.trueknn(pts, k, r0)
+    assert ref["rounds"] >= 2, "the case must need a second launch"
+    assert "rounds=%d " % ref["rounds"] in r.stdout, r.stdout
+    assert "held_marker=ok" in r.stdout, r.stdout
+    fb = np.frombuffer(out.read_bytes(), dtype=oracle.NEIGH_DTYPE).reshape(n, k)
+    assert np.array_equal(fb["dist"], ref["dist"])
+    assert np.array_equal(fb["intersections"][:, 0], ref["intersections"])
+    assert np.all(fb["intersections"][:, 1:] == 0)
+    assert np.all(fb["numNeighbors"][:, 0] == 0)
+
+
+@pytest.mark.gpu
 def test_unchanged_reference_sample_runs(tmp_path):
     """samples/s01-trueknn (hostCode.cpp + deviceCode.cu, unchanged) linked against libowl_mi355x."""
     if not os.path.exists(REF_SAMPLE):
