@@ -122,6 +122,7 @@ struct TeamArgs {
   int max_rounds;
   int allow_unfinished;
   int first_step;  // levels the first gather of every packet serves (density estimate, 1..kMaxStep)
+  int first_ext;   // ... and whether that gather also lists the blocks of the level after them (see the level loop)
   float tie_span;  // sqrt(number of axes along which the points differ), rounded up: d <= tie_span * Chebyshev distance
   int diag;        // TKNN_DIAG_BUILD only: 1 skip inserts, 2 skip SELECT passes, 4 skip COUNT passes, 8 skip per-block query tests,
                    // 16 / 32 step and gather statistics (atomics: slow), 64 every block visit of a query reads its first listed block
@@ -350,19 +351,26 @@ __device__ __forceinline__ void team_pass(const TeamArgs &a, const TeamLds &L, i
     // list: near blocks first tightens the k-th-distance gate early (about 30 % fewer inserts than
     // list order on uniform data) and changes nothing else -- the result does not depend on order.
     // COUNT takes the list as it is.
+    // A list that serves the level AFTER the step it was gathered for (see team_kernel) is "the step's blocks in Morton
+    // order, then the rest": outward order inside the first part (bits 16..23 of the record; 0: the whole list), the
+    // rest as listed -- farther than every block of the first part anyway.
     const int own_pos = (packed >> 8) & 0xff;
-    const int both = min(own_pos, last - own_pos);
-    const bool right_longer = last - own_pos > own_pos;
+    const int n_near = (packed >> 16) & 0xff;
+    const int last_near = n_near ? n_near - 1 : last;
+    const int both = min(own_pos, last_near - own_pos);
+    const bool right_longer = last_near - own_pos > own_pos;
     auto list_pos = [&](int it) -> int {
       if (!SELECT) return it;
       const int half = (it + 1) >> 1;
       const int alt = (it & 1) ? half : -half;  // it = 0: own block
       const int far = it - both;
       const int off = it <= 2 * both ? alt : (right_longer ? far : -far);
-      return own_pos + off;
+      return it > last_near ? it : own_pos + off;
     };
     auto list_entry = [&](int pos) -> int32_t {
-      const int at = min(max(list_pos(pos), 0), kMaxPerQuery - 1);
+      int lp = list_pos(pos);
+      if (n_near && lp >= n_near) lp = kMaxPerQuery - 1 - (lp - n_near);  // the back part, filled downwards
+      const int at = min(max(lp, 0), kMaxPerQuery - 1);
       int32_t e = L.blk[mine[at]];
       if (TKNN_DIAG_BUILD && (a.diag & 64)) e = L.blk[mine[0]];  // every visit reads one and the same block: what do cache misses cost?
       return resolve_entry<HALO>(pos <= last ? e : nan_block);
@@ -794,6 +802,16 @@ __global__ void __launch_bounds__(kTeamBlock) __attribute__((amdgpu_waves_per_eu
     L.cand = cand;
     L.cand_n = cand_n;
 
+    // One gather may serve MORE than the step it is made for: when the queries are unlikely all to finish inside the step
+    // (levels level .. level+m-1), the walk is made at the radius of the level after it ("extension"), and every block a
+    // query needs is listed either at the front of its list (needed inside the step) or at its back (needed at the
+    // extension level only).  The step's passes work on the front parts; the next turn of the level loop then finds its
+    // lists in LDS (`reuse`) and runs its passes without a walk of its own -- at BASELINE config 2 (levels 0 and 1 share a
+    // step, 59 % of the queries go on to level 2) one pyramid walk per packet instead of two.  A packet whose extended
+    // lists do not fit walks again for the step alone.
+    bool reuse = false;          // wave-uniform: this level's lists are in LDS already
+    int ext_next = a.first_ext;  // wave-uniform: extend the next gather
+    bool ext_ok = a.first_ext >= 0;  // ... no more for this packet once its extended lists did not fit (its boxes only grow); < 0: never
     for (;;) {  // radius levels
       PHASE_END(4);
       // ---- 1. query records, conservative query boxes ---------------------------------------
@@ -804,28 +822,55 @@ __global__ void __launch_bounds__(kTeamBlock) __attribute__((amdgpu_waves_per_eu
       step = __builtin_amdgcn_readfirstlane(step);
       if (!a.start_radii) r = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(r)));
       int m = step < 1 ? 1 : (step > kMaxStep ? kMaxStep : step);
+      if (reuse) m = 1;  // the extension level of the previous gather
       if (level + m > a.max_rounds) m = a.max_rounds - level;
       const float r_in0 = r;                        // radius of the inner level of a two-level step
       float r_out = r;
       for (int j = 1; j < m; j++) r_out = r_out * 2.0f;
-      // conservative query boxes for the gather: every literal candidate of q at r_out lies inside
-      float lo_x = INFINITY, lo_y = INFINITY, lo_z = INFINITY, hi_x = -INFINITY, hi_y = -INFINITY, hi_z = -INFINITY;
       {
-        const float mg = (fmaxf(fmaxf(fabsf(q.x), fabsf(q.y)), fabsf(q.z)) + 2.0f * r_out) * 4.76837158203125e-07f;  // 2^-21
-        if (active && q.x == q.x) {  // (a NaN query -- lbvh.hip makes every coordinate NaN -- keeps the empty box: it needs no block)
-          lo_x = (q.x - r_out) - 2.0f * mg;
-          lo_y = (q.y - r_out) - 2.0f * mg;
-          lo_z = (q.z - r_out) - 2.0f * mg;
-          hi_x = (q.x + r_out) + 2.0f * mg;
-          hi_y = (q.y + r_out) + 2.0f * mg;
-          hi_z = (q.z + r_out) + 2.0f * mg;
-        }
         float *rec = qrec + lane * kQrecStride;
         rec[0] = q.x;
         rec[1] = q.y;
         rec[2] = q.z;
         rec[3] = __int_as_float(q.id);
         rec[4] = r_out;
+      }
+      int my_nblk = 0;  // lane = query: how many blocks of the packet's list this turn's passes visit for me
+      int n_in = 0, n_out = 0;  // ... of my list: needed inside the step (its front part) / at the extension level only (its back)
+      int my_own_pos = 0;       // ... and where my own block (the one holding me) sits in the front part
+      bool too_big = false;  // this packet-level does not fit the LDS lists
+      bool ext = !reuse && ext_next > 0 && level + m < a.max_rounds;
+      ext = __builtin_amdgcn_readfirstlane((int)ext) != 0;
+      if (reuse) {
+        // front part + back part (team_pass maps positions past the front part to the back of the list); their lengths
+        // wait in my record -- three more registers live across the passes would spill
+        const int pk = __float_as_int(qrec[lane * kQrecStride + 5]);
+        n_in = pk & 0xff;
+        my_own_pos = (pk >> 8) & 0xff;
+        n_out = (pk >> 24) & 0xff;
+        my_nblk = n_in + n_out;
+        reuse = false;
+      } else
+      for (;;) {  // the walk; a second time, for the step alone, if the extended lists do not fit
+      const float r_walk = ext ? r_out * 2.0f : r_out;
+      // conservative query boxes for the gather: every literal candidate of q at r_walk lies inside
+      float lo_x = INFINITY, lo_y = INFINITY, lo_z = INFINITY, hi_x = -INFINITY, hi_y = -INFINITY, hi_z = -INFINITY;
+      // ... and, per query, how far a block's box may be from the query POINT (largest per-axis gap) to be needed at the
+      // walk's radius / inside the step: radius plus the margin of the candidate test (-inf: a query that needs nothing)
+      float reach_walk = -INFINITY, reach_step = -INFINITY;
+      {
+        const float qabs = fmaxf(fmaxf(fabsf(q.x), fabsf(q.y)), fabsf(q.z));
+        const float mg = (qabs + 2.0f * r_walk) * 4.76837158203125e-07f;  // 2^-21
+        if (active && q.x == q.x) {  // (a NaN query -- lbvh.hip makes every coordinate NaN -- keeps the empty box: it needs no block)
+          lo_x = (q.x - r_walk) - 2.0f * mg;
+          lo_y = (q.y - r_walk) - 2.0f * mg;
+          lo_z = (q.z - r_walk) - 2.0f * mg;
+          hi_x = (q.x + r_walk) + 2.0f * mg;
+          hi_y = (q.y + r_walk) + 2.0f * mg;
+          hi_z = (q.z + r_walk) + 2.0f * mg;
+          reach_walk = r_walk + 2.0f * mg;
+          reach_step = ext ? r_out + 2.0f * ((qabs + 2.0f * r_out) * 4.76837158203125e-07f) : reach_walk;
+        }
       }
       // The pyramid is culled against FOUR boxes, one per 16 Morton-consecutive queries (= one leaf
       // block of queries), not against the packet's one union box: where the Z-curve jumps, or
@@ -874,18 +919,18 @@ __global__ void __launch_bounds__(kTeamBlock) __attribute__((amdgpu_waves_per_eu
         dst[2] = make_float2(bx.hi[1], bx.hi[2]);
         t_wave_sync();
       };
-      auto needed_by_me = [&](int src) -> bool {  // does the child in lane `src` meet MY query box?
+      // the largest per-axis gap between the child box in lane `src` and MY query point (<= 0: I am inside): the child is
+      // needed at radius R iff gap <= R (+ the margin: reach_*).  One distance serves the walk's radius and the step's.
+      auto gap_to_me = [&](int src) -> float {
         const float2 *b = (const float2 *)(node_boxes + 6 * src);
         const float2 b0 = b[0], b1 = b[1], b2 = b[2];
-        return separation(b0.x, b0.y, b1.x, b1.y, b2.x, b2.y, lo_x, lo_y, lo_z, hi_x, hi_y, hi_z) <= 0.f;
+        return separation(b0.x, b0.y, b1.x, b1.y, b2.x, b2.y, q.x, q.y, q.z, q.x, q.y, q.z);
       };
 
       PHASE_END(0);
       // ---- 2+3. gather the packet's block list and the per-query masks ----------------------
-      int my_nblk = 0;  // lane = query: how many blocks of the packet's list I need
-      int my_own_pos = 0;  // ... and where my own block (the one holding me) sits in my list
+      n_in = 0, n_out = 0, my_own_pos = 0;
       int nb = 0, scanned = 0;
-      bool too_big = false;  // this packet-level does not fit the LDS lists
       for (int tree = 0; tree < 2 && !too_big; tree++) {
         const LbvhWideView &wv = a.wide[tree];
         const int32_t tree_n = tree == 0 ? a.bvh.n : a.halo.n;
@@ -930,7 +975,7 @@ __global__ void __launch_bounds__(kTeamBlock) __attribute__((amdgpu_waves_per_eu
               while (rest) {
                 const int src = 63 - __builtin_clzll(rest);
                 rest &= ~(1ull << src);
-                if (__ballot(needed_by_me(src)) == 0ull) continue;
+                if (__ballot(gap_to_me(src) <= reach_walk) == 0ull) continue;
                 if (lane == 0) stack[kTeamStack - 1 - nleaf] = (lvl << 26) | (first_child + src);
                 nleaf++;
               }
@@ -965,12 +1010,13 @@ __global__ void __launch_bounds__(kTeamBlock) __attribute__((amdgpu_waves_per_eu
               too_big = true;
               break;
             }
-            // leaf blocks: which of my 64 queries need block c?  (lanes = queries, box by v_readlane)
+            // leaf blocks: which of my 64 queries need block c?  (lanes = queries, box from LDS)
             if (om) stash_boxes(bx);
             while (om) {
               const int src = __ffsll((long long)om) - 1;
               om &= om - 1;
-              bool need = needed_by_me(src);
+              const float gap = gap_to_me(src);
+              bool need = gap <= reach_walk;
               if (TKNN_DIAG_BUILD && (a.diag & 8)) need = false;
               if (__ballot(need) == 0ull) continue;
               if (nb >= kMaxBlocks) {
@@ -979,9 +1025,14 @@ __global__ void __launch_bounds__(kTeamBlock) __attribute__((amdgpu_waves_per_eu
               }
               if (lane == 0) blk[nb] = (int32_t)((uint32_t)(first_child + src) | ((uint32_t)tree << 31));
               if (need) {
-                if (my_nblk < kMaxPerQuery) qblk[lane * kMaxPerQuery + my_nblk] = (uint8_t)nb;
-                if (tree == 0 && first_child + src == (slot >> 4)) my_own_pos = my_nblk;
-                my_nblk++;
+                // inside the step: the front of my list, upwards; at the extension level only: its back, downwards
+                const bool inner = gap <= reach_step;
+                const bool room = n_in + n_out < kMaxPerQuery;
+                const int at = inner ? n_in : kMaxPerQuery - 1 - n_out;
+                if (room) qblk[lane * kMaxPerQuery + at] = (uint8_t)nb;
+                if (tree == 0 && first_child + src == (slot >> 4)) my_own_pos = n_in;
+                n_in += inner ? 1 : 0;
+                n_out += inner ? 0 : 1;
               }
               nb++;
             }
@@ -991,6 +1042,23 @@ __global__ void __launch_bounds__(kTeamBlock) __attribute__((amdgpu_waves_per_eu
         }
         t_wave_sync();  // the stack array is rewritten by the next tree / shared with the passes
       }
+      if (TKNN_DIAG_BUILD && (a.diag & 32)) diag_listed += nb;
+      if (ext) {
+        // extended lists that do not fit (a list longer than its slots, more blocks than the packet's list names, the
+        // scan budget): once more, for the step alone
+        if (too_big || __ballot(n_in + n_out > kMaxPerQuery) != 0ull) {
+          ext = false;
+          ext_ok = false;
+          too_big = false;
+          t_wave_sync();
+          continue;
+        }
+        reuse = __ballot(active) != 0ull;
+      }
+      my_nblk = n_in;
+      if (!ext) n_out = 0;
+      break;
+      }  // the walk
       // The packet's block list or scan budget is exhausted, or a query needs more blocks than its own
       // list holds: the packet's unfinished queries are handed over (team walk / lane rounds / wave
       // kernel, see solve_team), from this level on.  With four list registers (k > 32: boxes of
@@ -1023,8 +1091,9 @@ __global__ void __launch_bounds__(kTeamBlock) __attribute__((amdgpu_waves_per_eu
         wave_min_handover = min(wave_min_handover, level);
         if (__ballot(active) == 0ull) break;
       }
-      if (TKNN_DIAG_BUILD && (a.diag & 32)) diag_listed += nb;
-      const int my_packed = my_nblk | (my_own_pos << 8);  // read back by the teams
+      // read back by the teams: list length | position of my own block | length of the front part if a back part follows
+      // (bits 24..31, which the teams ignore: the back part's length while the step's passes run on the front part)
+      const int my_packed = my_nblk | (my_own_pos << 8) | (my_nblk > n_in ? n_in << 16 : n_out << 24);
       qrec[lane * kQrecStride + 5] = __int_as_float(my_packed);
 
       PHASE_END(1);
@@ -1144,6 +1213,9 @@ __global__ void __launch_bounds__(kTeamBlock) __attribute__((amdgpu_waves_per_eu
           step++;
           expect *= 8.f;
         }
+        // ... and list the blocks of the level after the step, too, unless even the best-off query will almost
+        // surely finish inside it (a packet walks again as long as ONE of its 64 queries is unfinished)
+        ext_next = ext_ok && expect < 2.5f * (float)a.k ? 1 : 0;
       }
     }
     if (active) my_unfinished++;
@@ -1822,6 +1894,14 @@ bool Engine::solve_team(const SolveArgs &sa, tknnSolveInfo *info, hipStream_t s)
   a.max_rounds = sa.max_rounds;
   a.allow_unfinished = sa.allow_unfinished ? 1 : 0;
   a.first_step = sa.d_start_radii ? 1 : first_step_estimate(sa);  // (the estimate is from ONE start radius and the mean density)
+  {
+    // the first gather also lists the blocks of the level after its step unless the boxes of the step's last level are
+    // expected to hold k others several times over (team_kernel: the same rule between later steps)
+    float radius = sa.start_radius;
+    for (int t = 1; t < std::min(a.first_step, kMaxStep); t++) radius *= 2.0f;
+    a.first_ext = !sa.d_start_radii && expected_box_population(radius) < 2.5 * sa.k ? 1 : 0;
+    if (const char *e = getenv("TKNN_TEAM_EXT")) a.first_ext = atoi(e) > 0 ? a.first_ext : -1;  // measurements: 0 = no extended gathers at all
+  }
   {
     // axes along which the built points differ at all (2-D inputs carry z = 0, hostCode.cpp:115-118);
     // a halo tree may hold anything
