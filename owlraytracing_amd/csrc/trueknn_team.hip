@@ -446,8 +446,12 @@ __device__ __forceinline__ void team_pass(const TeamArgs &a, const TeamLds &L, i
       for (int row = 0; row < kCandCap / 16; row++) {
         if (row > 0 && __ballot(fill > 16u * (uint32_t)row) == 0ull) break;
         const uint32_t at = 16u * (uint32_t)row + (uint32_t)tl;
-        const unsigned long long key = at < fill ? L.cand[team * kCandCap + at] : KNN_EMPTY_KEY;
-        uint32_t kd = (uint32_t)(key >> 32), ki = (uint32_t)key;
+        // the buffer holds (squared distance, index): the IEEE square root -- sixteen instructions -- is taken here, once
+        // per merged row, not at every block that has a candidate for some team (four of five blocks on the benchmark)
+        const bool have = at < fill;
+        const unsigned long long key = have ? L.cand[team * kCandCap + at] : 0ull;
+        const float dist = knn_sqrt(__uint_as_float((uint32_t)(key >> 32)));
+        uint32_t kd = have ? __float_as_uint(dist) : 0x7f7fffffu, ki = have ? (uint32_t)key : 0u;  // KNN_EMPTY_KEY past the end
         sort16(kd, ki);
         const uint32_t od = t_dpp<0x140>(kd), oi = t_dpp<0x140>(ki);  // sorted key 15 - tl
         const uint64_t mine_k = ((uint64_t)bd[0] << 32) | bi[0], other = ((uint64_t)od << 32) | oi;
@@ -495,11 +499,11 @@ __device__ __forceinline__ void team_pass(const TeamArgs &a, const TeamLds &L, i
         if (NREG == 1) {
           if (pm) {
             if (TKNN_DIAG_BUILD && (a.diag & 16) && lane == 0) atomicAdd(&a.counters[26], (unsigned long long)__popcll(pm));
-            // my candidate's exact key into the team's buffer; a full row of sixteen is merged at once (a block
+            // my candidate into the team's buffer; a full row of sixteen is merged at once (a block
             // adds at most sixteen to at most fifteen: the buffer holds 32)
             bool row_full = false;
             if ((pm >> lane) & 1ull) {
-              const unsigned long long key = ((unsigned long long)__float_as_uint(knn_sqrt(d2)) << 32) | (uint32_t)p.id;
+              const unsigned long long key = ((unsigned long long)__float_as_uint(d2) << 32) | (uint32_t)p.id;  // (the root: merge_buffer)
               const uint32_t slot = __hip_atomic_fetch_add(&L.cand_n[team], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
               L.cand[team * kCandCap + slot] = key;
               row_full = slot >= 15u;
