@@ -926,14 +926,20 @@ __global__ void __launch_bounds__(kTeamBlock) __attribute__((amdgpu_waves_per_eu
       // the largest per-axis gap between the child box in lane `src` and MY query point (<= 0: I am inside): the child is
       // needed at radius R iff gap <= R (+ the margin: reach_*).  One distance serves the walk's radius and the step's.
       auto gap_to_me = [&](int src) -> float {
-        const float2 *b = (const float2 *)(node_boxes + 6 * src);
+        // (src is wave-uniform: its byte offset is a scalar product -- left to itself the compiler folds the product and
+        // the address add into one v_mad_u64_u32, a quarter-rate instruction, for every block tested)
+        int boff;
+        asm("s_mul_i32 %0, %1, 24" : "=s"(boff) : "s"(src));
+        const float2 *b = (const float2 *)((const char *)node_boxes + boff);
         const float2 b0 = b[0], b1 = b[1], b2 = b[2];
         return separation(b0.x, b0.y, b1.x, b1.y, b2.x, b2.y, q.x, q.y, q.z, q.x, q.y, q.z);
       };
 
       PHASE_END(0);
       // ---- 2+3. gather the packet's block list and the per-query masks ----------------------
-      n_in = 0, n_out = 0, my_own_pos = 0;
+      my_own_pos = 0;
+      int cur = 0;  // lane = query: blocks in the front part of my list | blocks in its back part << 16
+      uint8_t *my_list = qblk + lane * kMaxPerQuery;
       int nb = 0, scanned = 0;
       for (int tree = 0; tree < 2 && !too_big; tree++) {
         const LbvhWideView &wv = a.wide[tree];
@@ -1027,16 +1033,17 @@ __global__ void __launch_bounds__(kTeamBlock) __attribute__((amdgpu_waves_per_eu
                 too_big = true;  // more blocks than a byte slot can name
                 break;
               }
-              if (lane == 0) blk[nb] = (int32_t)((uint32_t)(first_child + src) | ((uint32_t)tree << 31));
+              const int32_t block = first_child + src;
+              blk[nb] = (int32_t)((uint32_t)block | ((uint32_t)tree << 31));  // (every lane stores the same word: no exec mask to set up)
+              // my own block is one of the packet's own four (a scalar test; its position: how many I have listed before it)
+              if (tree == 0 && (uint32_t)(block - g * 4) < 4u && block == (slot >> 4)) my_own_pos = cur & 0xffff;
               if (need) {
-                // inside the step: the front of my list, upwards; at the extension level only: its back, downwards
+                // inside the step: the front of my list, upwards; at the extension level only: its back, downwards.  A list
+                // that outgrows its slots keeps writing inside them (clamped): the packet walks again or is handed over.
                 const bool inner = gap <= reach_step;
-                const bool room = n_in + n_out < kMaxPerQuery;
-                const int at = inner ? n_in : kMaxPerQuery - 1 - n_out;
-                if (room) qblk[lane * kMaxPerQuery + at] = (uint8_t)nb;
-                if (tree == 0 && first_child + src == (slot >> 4)) my_own_pos = n_in;
-                n_in += inner ? 1 : 0;
-                n_out += inner ? 0 : 1;
+                const int at = inner ? (cur & 0xffff) : kMaxPerQuery - 1 - (cur >> 16);
+                my_list[min(max(at, 0), kMaxPerQuery - 1)] = (uint8_t)nb;  // (v_med3_i32)
+                cur += inner ? 1 : 0x10000;
               }
               nb++;
             }
@@ -1047,6 +1054,7 @@ __global__ void __launch_bounds__(kTeamBlock) __attribute__((amdgpu_waves_per_eu
         t_wave_sync();  // the stack array is rewritten by the next tree / shared with the passes
       }
       if (TKNN_DIAG_BUILD && (a.diag & 32)) diag_listed += nb;
+      n_in = cur & 0xffff, n_out = cur >> 16;
       if (ext) {
         // extended lists that do not fit (a list longer than its slots, more blocks than the packet's list names, the
         // scan budget): once more, for the step alone
