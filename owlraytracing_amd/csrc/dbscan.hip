@@ -231,8 +231,16 @@ __device__ __forceinline__ void db_core_body(const DbArgs &a, int32_t t, uint32_
   const int32_t clean_end = bvh.n - (bvh.nan_count ? *bvh.nan_count : 0);  // NaN points sort last
   const float r = a.eps_wide;
   int32_t ref = bvh.root;
+  // the last nodes above my group on my root path (anc[0]: kNear levels above it).  A point whose group is too small to
+  // decide looks for its minPts neighbours there FIRST: they are next to it, a walk from the root spends two dozen steps
+  // getting near (BASELINE config 3: a fifth of the points walk, nearly all of them core, 0.9 of the pass's 1.4 ms).
+  constexpr int kNear = 4;
+  int32_t anc[kNear];
+#pragma unroll
+  for (int j = 0; j < kNear; j++) anc[j] = bvh.root;
   if (!a.want_counts || a.group_of) {
     int32_t node = bvh.root, first = t;
+    if (TKNN_DIAG_BUILD && (a.diag & 128)) node = -1;  // (times only) no descent to the group
     while (node >= 0) {
       const LbvhNode nd = bvh.nodes[node];
       node_tests++;
@@ -245,35 +253,60 @@ __device__ __forceinline__ void db_core_body(const DbArgs &a, int32_t t, uint32_
         }
         break;
       }
+#pragma unroll
+      for (int j = 0; j + 1 < kNear; j++) anc[j] = anc[j + 1];
+      anc[kNear - 1] = node;
       node = t <= nd.split ? lbvh_left_ref(node, nd) : lbvh_right_ref(node, nd);
     }
     // the group's first slot keeps the group's reference (a node, or ~t for a point by itself), the others ~first
     if (a.group_of) a.group_of[t] = t == first ? (node >= 0 ? node : ~t) : ~first;
   }
-  while (ref != LBVH_END && cnt < stop_at) {
-    if (ref >= 0) {
-      const LbvhNode nd = bvh.nodes[ref];
-      node_tests++;
-      const bool hit = (nd.lo[0] - r <= q.x) & (q.x <= nd.hi[0] + r) & (nd.lo[1] - r <= q.y) & (q.y <= nd.hi[1] + r) &
-                       (nd.lo[2] - r <= q.z) & (q.z <= nd.hi[2] + r);
-      if (hit) {
-        // a node inside the sphere is counted, not walked
-        float far2, near2;
-        box_dist2(nd, q, far2, near2);
-        const int32_t last = lbvh_last(ref, nd.other);
-        if (far2 <= a.eps_in2 && last < clean_end) {
-          cnt += last - lbvh_first(ref, nd.other) + 1;
-          ref = bvh.rope_node[ref];
-          continue;
+  if (TKNN_DIAG_BUILD && (a.diag & 64)) ref = LBVH_END;  // (times only) no neighbour count
+  // rope walk from `from` until the walk would leave through `until` (the rope of the subtree's root; LBVH_END: the whole tree)
+  auto count_from = [&](int32_t from, int32_t until) {
+    int32_t at = from;
+    while (at != until && cnt < stop_at) {
+      if (at >= 0) {
+        // the rope is fetched WITH the node, not after the box test has asked for it: a walk is a chain of dependent loads
+        // (a wave lives as long as its longest walk), and this halves the chain for four more bytes per step
+        const LbvhNode nd = bvh.nodes[at];
+        const int32_t rope = bvh.rope_node[at];
+        node_tests++;
+        const bool hit = (nd.lo[0] - r <= q.x) & (q.x <= nd.hi[0] + r) & (nd.lo[1] - r <= q.y) & (q.y <= nd.hi[1] + r) &
+                         (nd.lo[2] - r <= q.z) & (q.z <= nd.hi[2] + r);
+        if (hit) {
+          // a node inside the sphere is counted, not walked
+          float far2, near2;
+          box_dist2(nd, q, far2, near2);
+          const int32_t last = lbvh_last(at, nd.other);
+          if (far2 <= a.eps_in2 && last < clean_end) {
+            cnt += last - lbvh_first(at, nd.other) + 1;
+            at = rope;
+            continue;
+          }
         }
+        at = hit ? lbvh_left_ref(at, nd) : rope;
+      } else {
+        const int32_t slot = ~at;
+        const LbvhPoint p = bvh.points[slot];
+        point_tests++;
+        if (knn_sqrt(knn_dist2(p.x, p.y, p.z, q.x, q.y, q.z)) <= a.eps) cnt++;
+        at = bvh.rope_leaf[slot];
       }
-      ref = hit ? lbvh_left_ref(ref, nd) : bvh.rope_node[ref];
+    }
+  };
+  if (ref != LBVH_END) {
+    const int32_t near = anc[0];
+    if (!a.want_counts && near != bvh.root && near >= 0) {
+      // enough neighbours in the subtree around me: core, whatever else the sphere holds.  Not enough: the count starts
+      // again over the whole tree (the subtree's points would be counted twice otherwise).
+      count_from(near, bvh.rope_node[near]);
+      if (cnt < a.min_pts) {
+        cnt = 0;
+        count_from(bvh.root, LBVH_END);
+      }
     } else {
-      const int32_t slot = ~ref;
-      const LbvhPoint p = bvh.points[slot];
-      point_tests++;
-      if (knn_sqrt(knn_dist2(p.x, p.y, p.z, q.x, q.y, q.z)) <= a.eps) cnt++;
-      ref = bvh.rope_leaf[slot];
+      count_from(bvh.root, LBVH_END);
     }
   }
   const uint8_t is_core = cnt >= a.min_pts;
@@ -281,7 +314,7 @@ __device__ __forceinline__ void db_core_body(const DbArgs &a, int32_t t, uint32_
   // results are indexed by ROW (the point's position in the caller's buffer, prim_id of the sorted
   // slot), not by the id an engine built with tknnBuildIds reports; the union-find by sorted slot
   const int32_t row = bvh.prim_id[t];
-  if (a.core) a.core[row] = is_core;
+  if (a.core && !(TKNN_DIAG_BUILD && (a.diag & 256))) a.core[row] = is_core;
   if (a.counts) a.counts[row] = cnt;
 }
 
@@ -814,8 +847,11 @@ __global__ void __launch_bounds__(kDbBlock) db_label_kernel(DbArgs a, int32_t *p
   const int32_t t = blockIdx.x * kDbBlock + threadIdx.x;
   bool walk = false;
   if (t < a.bvh.n) {
-    if (a.core_sorted[t])
-      a.labels[a.bvh.prim_id[t]] = a.rank[a.min_row[uf_find(a.parent, t)]];  // (mostly one step: db_flatten_kernel has pointed the slots at their roots)
+    const int32_t row = a.bvh.prim_id[t];
+    const uint8_t is_core = a.core_sorted[t];
+    if (a.core) a.core[row] = is_core;
+    if (is_core)
+      a.labels[row] = a.rank[a.min_row[uf_find(a.parent, t)]];  // (mostly one step: db_flatten_kernel has pointed the slots at their roots)
     else
       walk = true;
   }
@@ -1053,7 +1089,11 @@ void Engine::dbscan(float eps, int min_pts, int32_t *d_labels, uint8_t *d_core, 
   if (core_label) {
     hipLaunchKernelGGL(db_core_from_labels_kernel, dim3(blocks), dim3(kDbBlock), 0, s, a, core_label);
   } else {
-    hipLaunchKernelGGL(db_core_kernel, dim3(blocks), dim3(kDbBlock), 0, s, a);
+    // the flags BY ROW are written by the label kernel, which scatters to the rows anyway: a one-byte store at the
+    // caller's row from this kernel cost a partial sector per point (rocprofv3: 426 MB written for 10 M points)
+    DbArgs c = a;
+    c.core = nullptr;
+    hipLaunchKernelGGL(db_core_kernel, dim3(blocks), dim3(kDbBlock), 0, s, c);
   }
   OWLMI_HIP(hipEventRecord(ev_c_, s));  // end of the core-flag traversal
   {
