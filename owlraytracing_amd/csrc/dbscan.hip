@@ -59,6 +59,7 @@ struct DbArgs {
   // tested, [2k + 1] points whose distance to a query was computed (12 algorithmic bytes each)
   unsigned long long *stats;
   int32_t *group_of;  // per sorted slot, written by the core-flag kernel (see db_group_kernel); null: not wanted
+  int32_t *near_node;  // per sorted slot, or null: the node a few levels above the point's group (written by the core-flag kernel for the noise probe)
   int chunk;  // packets per chunk dealt to an XCD (db_group_union_kernel)
   int scan_budget;  // steps the quick scan of a probe may take before the subtrees are asked (db_group_union_kernel)
   float reach, near_lo2, near_hi2;  // this pass of db_group_union_kernel: groups whose nearest faces are near_lo2 < d^2 <= near_hi2 apart, reach >= sqrt(near_hi2)
@@ -148,11 +149,12 @@ __device__ __forceinline__ void for_each_core_group(const DbArgs &a, const LbvhP
     if (probe_rep >= 0 && ref == probe_exit) probe_rep = -1;  // left the probed subtree without a hit
     if (ref >= 0) {
       const LbvhNode nd = bvh.nodes[ref];
+      const int32_t rope = bvh.rope_node[ref];  // with the node, not after it: half the chain of dependent loads
       node_tests++;
       const bool hit = (nd.lo[0] - r <= q.x) & (q.x <= nd.hi[0] + r) & (nd.lo[1] - r <= q.y) & (q.y <= nd.hi[1] + r) &
                        (nd.lo[2] - r <= q.z) & (q.z <= nd.hi[2] + r);
       if (!hit) {
-        ref = bvh.rope_node[ref];
+        ref = rope;
         continue;
       }
       const bool probing = probe_rep >= 0;
@@ -160,35 +162,37 @@ __device__ __forceinline__ void for_each_core_group(const DbArgs &a, const LbvhP
         const int32_t first = lbvh_first(ref, nd.other), last = lbvh_last(ref, nd.other);
         const int32_t s = a.next_core[first];
         if (s > last || (first <= own_slot && own_slot <= last)) {  // no core point here / my own group
-          ref = bvh.rope_node[ref];
+          ref = rope;
           continue;
         }
         if (!probing && settled(s)) {
-          ref = bvh.rope_node[ref];
+          ref = rope;
           continue;
         }
         float far2, near2;
         box_dist2(nd, q, far2, near2);
         if (far2 <= a.eps_in2) {  // every point of the node is within eps
           f(probing ? probe_rep : s);
-          ref = probing ? probe_exit : bvh.rope_node[ref];
+          ref = probing ? probe_exit : rope;
           probe_rep = -1;
           continue;
         }
         if (near2 > a.eps_out2) {  // none is
-          ref = bvh.rope_node[ref];
+          ref = rope;
           continue;
         }
         if (!probing) {
           probe_rep = s;
-          probe_exit = bvh.rope_node[ref];
+          probe_exit = rope;
         }
       }
       ref = lbvh_left_ref(ref, nd);
     } else {
       const int32_t slot = ~ref;
-      if (a.core_sorted[slot] && slot != own_slot) {
-        const LbvhPoint p = bvh.points[slot];
+      const uint8_t is_core = a.core_sorted[slot];  // three independent loads at once (nearly every leaf reached is core)
+      const LbvhPoint p = bvh.points[slot];
+      const int32_t rope = bvh.rope_leaf[slot];
+      if (is_core && slot != own_slot) {
         point_tests++;
         if (knn_sqrt(knn_dist2(p.x, p.y, p.z, q.x, q.y, q.z)) <= a.eps) {
           if (probe_rep >= 0) {
@@ -200,7 +204,7 @@ __device__ __forceinline__ void for_each_core_group(const DbArgs &a, const LbvhP
           f(slot);
         }
       }
-      ref = bvh.rope_leaf[slot];
+      ref = rope;
     }
   }
 }
@@ -223,7 +227,7 @@ __device__ __forceinline__ void db_append(bool flag, int32_t value, int32_t *lis
 // pass took 2.2 ms instead of 1.45.)
 __device__ __forceinline__ void db_core_body(const DbArgs &a, int32_t t, uint32_t &node_tests, uint32_t &point_tests) {
   const LbvhView &bvh = a.bvh;
-  a.parent[t] = t;
+  if (a.parent) a.parent[t] = t;
   if (a.keep_core && a.core_sorted[t]) return;
   const LbvhPoint q = bvh.points[t];
   int32_t cnt = 0;
@@ -260,12 +264,17 @@ __device__ __forceinline__ void db_core_body(const DbArgs &a, int32_t t, uint32_
     }
     // the group's first slot keeps the group's reference (a node, or ~t for a point by itself), the others ~first
     if (a.group_of) a.group_of[t] = t == first ? (node >= 0 ? node : ~t) : ~first;
+    if (a.near_node) a.near_node[t] = anc[0];
   }
   if (TKNN_DIAG_BUILD && (a.diag & 64)) ref = LBVH_END;  // (times only) no neighbour count
   // rope walk from `from` until the walk would leave through `until` (the rope of the subtree's root; LBVH_END: the whole tree)
-  auto count_from = [&](int32_t from, int32_t until) {
+  auto count_from = [&](int32_t from, int32_t until, int32_t skip, int32_t skip_rope) {
     int32_t at = from;
     while (at != until && cnt < stop_at) {
+      if (at == skip) {  // the subtree counted already
+        at = skip_rope;
+        continue;
+      }
       if (at >= 0) {
         // the rope is fetched WITH the node, not after the box test has asked for it: a walk is a chain of dependent loads
         // (a wave lives as long as its longest walk), and this halves the chain for four more bytes per step
@@ -298,15 +307,13 @@ __device__ __forceinline__ void db_core_body(const DbArgs &a, int32_t t, uint32_
   if (ref != LBVH_END) {
     const int32_t near = anc[0];
     if (!a.want_counts && near != bvh.root && near >= 0) {
-      // enough neighbours in the subtree around me: core, whatever else the sphere holds.  Not enough: the count starts
-      // again over the whole tree (the subtree's points would be counted twice otherwise).
-      count_from(near, bvh.rope_node[near]);
-      if (cnt < a.min_pts) {
-        cnt = 0;
-        count_from(bvh.root, LBVH_END);
-      }
+      // enough neighbours in the subtree around me: core, whatever else the sphere holds.  Not enough: the count goes on
+      // over the rest of the tree (the walk from the root steps over that subtree).
+      const int32_t near_rope = bvh.rope_node[near];
+      count_from(near, near_rope, LBVH_END, LBVH_END);
+      if (cnt < a.min_pts) count_from(bvh.root, LBVH_END, near, near_rope);  // the rest of the tree
     } else {
-      count_from(bvh.root, LBVH_END);
+      count_from(bvh.root, LBVH_END, LBVH_END, LBVH_END);
     }
   }
   const uint8_t is_core = cnt >= a.min_pts;
@@ -915,39 +922,57 @@ __global__ void __launch_bounds__(kDbBlock) db_assign_kernel(DbArgs a, const int
 // not core itself?  One traversal with an early exit; a subtree without a core point (next_core) is skipped, a node
 // wholly inside the sphere that holds one settles the question.  Points found not to be noise never are again (a core
 // point stays core as eps grows), so later rounds probe the remaining noise only.
-__device__ __forceinline__ bool db_has_core_neighbour(const DbArgs &a, const LbvhPoint &q, uint32_t &node_tests, uint32_t &point_tests) {
+__device__ __forceinline__ bool db_has_core_neighbour(const DbArgs &a, const LbvhPoint &q, int32_t from, int32_t until, int32_t skip,
+                                                      int32_t skip_rope, uint32_t &node_tests, uint32_t &point_tests) {
   const LbvhView &bvh = a.bvh;
   const float r = a.eps_wide;
-  int32_t ref = bvh.root;
-  while (ref != LBVH_END) {
+  int32_t ref = from;
+  while (ref != until) {
+    if (ref == skip) {  // the subtree searched already
+      ref = skip_rope;
+      continue;
+    }
     if (ref >= 0) {
       const LbvhNode nd = bvh.nodes[ref];
+      const int32_t rope = bvh.rope_node[ref];  // with the node: half the chain of dependent loads
       node_tests++;
       const bool hit = (nd.lo[0] - r <= q.x) & (q.x <= nd.hi[0] + r) & (nd.lo[1] - r <= q.y) & (q.y <= nd.hi[1] + r) &
                        (nd.lo[2] - r <= q.z) & (q.z <= nd.hi[2] + r);
       if (!hit || a.next_core[lbvh_first(ref, nd.other)] > lbvh_last(ref, nd.other)) {  // out of reach, or no core point below
-        ref = bvh.rope_node[ref];
+        ref = rope;
         continue;
       }
       float far2, near2;
       box_dist2(nd, q, far2, near2);
       if (far2 <= a.eps_in2) return true;  // all of it within eps, and a core point among it
       if (near2 > a.eps_out2) {
-        ref = bvh.rope_node[ref];
+        ref = rope;
         continue;
       }
       ref = lbvh_left_ref(ref, nd);
     } else {
       const int32_t slot = ~ref;
-      if (a.core_sorted[slot]) {
-        const LbvhPoint p = bvh.points[slot];
+      const uint8_t is_core = a.core_sorted[slot];
+      const LbvhPoint p = bvh.points[slot];
+      const int32_t rope = bvh.rope_leaf[slot];
+      if (is_core) {
         point_tests++;
         if (knn_sqrt(knn_dist2(p.x, p.y, p.z, q.x, q.y, q.z)) <= a.eps) return true;
       }
-      ref = bvh.rope_leaf[slot];
+      ref = rope;
     }
   }
   return false;
+}
+// ... first in the subtree a few levels above the point's own group (the core-flag kernel has left its root in near_node): a
+// point that is not noise has its core neighbour next to it, and a walk from the root spends two dozen steps getting there
+__device__ __forceinline__ bool db_has_core_neighbour(const DbArgs &a, const LbvhPoint &q, int32_t t, uint32_t &node_tests, uint32_t &point_tests) {
+  const LbvhView &bvh = a.bvh;
+  const int32_t near = a.near_node ? a.near_node[t] : bvh.root;
+  if (near < 0 || near == bvh.root) return db_has_core_neighbour(a, q, bvh.root, LBVH_END, LBVH_END, LBVH_END, node_tests, point_tests);
+  const int32_t near_rope = bvh.rope_node[near];
+  if (db_has_core_neighbour(a, q, near, near_rope, LBVH_END, LBVH_END, node_tests, point_tests)) return true;
+  return db_has_core_neighbour(a, q, bvh.root, LBVH_END, near, near_rope, node_tests, point_tests);  // the rest of the tree
 }
 
 // noise[slot] (per sorted slot): in, unless first_round: 1 = was noise in the round before; out: 1 = is noise now.
@@ -962,7 +987,7 @@ __global__ void __launch_bounds__(kDbBlock) db_noise_probe_kernel(DbArgs a, uint
     if (a.core_sorted[t]) {
       noise[t] = 0;
     } else if (first_round || noise[t]) {
-      still = db_has_core_neighbour(a, a.bvh.points[t], node_tests, point_tests) ? 0u : 1u;
+      still = db_has_core_neighbour(a, a.bvh.points[t], t, node_tests, point_tests) ? 0u : 1u;
       noise[t] = (uint8_t)still;
     }
   }
@@ -1011,7 +1036,8 @@ int64_t Engine::dbscan_noise(float eps, int min_pts, uint8_t *d_noise, hipStream
   a.eps_wide = eps * 1.000001f;
   a.eps_in2 = eps * eps * (1.0f - 1e-5f);
   a.eps_out2 = eps * eps * (1.0f + 1e-5f);
-  a.parent = (int32_t *)ws;
+  a.parent = nullptr;            // no unions here: the slots' place holds ...
+  a.near_node = (int32_t *)ws;   // ... where each point's noise probe starts (db_has_core_neighbour)
   int32_t *core_rank = (int32_t *)(ws + (size_t)n * 4);
   a.rank = (int32_t *)(ws + (size_t)n * 8);                   // n + 1 entries: flags, then positions
   int32_t *next_core = (int32_t *)(ws + (size_t)n * 12 + 4);  // n + 1 entries
@@ -1056,6 +1082,7 @@ void Engine::dbscan(float eps, int min_pts, int32_t *d_labels, uint8_t *d_core, 
   }
   char *ws = (char *)wave_ws_;
   DbArgs a;
+  std::memset(&a, 0, sizeof a);
   a.bvh = bvh_.view();
   a.eps = eps;
   a.eps_wide = eps * 1.000001f;
@@ -1257,7 +1284,8 @@ void Engine::dbscan_auto(float eps0, int min_pts, double max_noise, int max_roun
   a.bvh = bvh_.view();
   a.min_pts = min_pts;
   a.keep_core = 1;
-  a.parent = (int32_t *)ws;
+  a.parent = nullptr;           // no unions in the growth rounds: the slots' place holds ...
+  a.near_node = (int32_t *)ws;  // ... where each point's noise probe starts (db_has_core_neighbour)
   int32_t *core_rank = (int32_t *)(ws + (size_t)n * 4);
   a.rank = (int32_t *)(ws + (size_t)n * 8);                     // n + 1 entries: flags, then positions
   int32_t *next_core = (int32_t *)(ws + (size_t)n * 12 + 4);  // n + 1 entries
