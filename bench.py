@@ -255,24 +255,32 @@ def main():
     if dist is not None:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    elapsed_own = elapsed
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        ones = torch.ones(1, dtype=torch.int64, device=dev)
-        dist.all_reduce(ones, op=dist.ReduceOp.SUM)
-        extra["ranks"] = int(ones.item())
-        # per-phase wall times of two more, instrumented steps (a device synchronisation after every phase, so
-        # they are not part of the timed region); maximum over the ranks of each phase's mean
+        last = infos[-1]
+        # one record per rank (an imbalance -- tile sizes come from 1 024 samples per rank -- must be visible in the one line
+        # a hardware run leaves): points, halo rows, exchanges, this rank's own step time, and the per-phase wall times of
+        # two more, instrumented steps (a device synchronisation after every phase, so they are not part of the timed region)
+        names = ["select", "exchange", "halo_build", "solve", "reduce"]
+        mine = [float(n_local), float(last.get("halo_points", 0)), float(last.get("halo_exchanges", 1 if dbscan else 0)), elapsed_own / args.steps * 1e3]
         if not dbscan:
             solver.profile = True
             ph = [solver.solve(k, r0)["phase_ms"] for _ in range(2)]
             solver.profile = False
-            names = sorted(ph[0])
-            v = torch.tensor([float(np.mean([p[nm] for p in ph])) for nm in names], dtype=torch.float64, device=dev)
-            dist.all_reduce(v, op=dist.ReduceOp.MAX)
-            extra["phase_ms"] = {nm: float(x) for nm, x in zip(names, v.tolist())}
-        last = infos[-1]
+            mine += [float(np.mean([p.get(nm, 0.0) for p in ph])) for nm in names]
+            mine.append(float(np.mean([i["dominant_kernel_ms"] for i in infos])))
+        v = torch.tensor(mine, dtype=torch.float64, device=dev if backend == "nccl" else "cpu")  # (gloo gathers host tensors only)
+        every = [torch.empty_like(v) for _ in range(world)]
+        dist.all_gather(every, v)
+        rows = [e.tolist() for e in every]
+        extra["ranks"] = [dict({"rank": j, "points": int(r_[0]), "halo_points": int(r_[1]), "halo_exchanges": int(r_[2]), "ms_per_step_own_clock": r_[3]},
+                               **({"phase_ms": {nm: r_[4 + i] for i, nm in enumerate(names)}, "kernel_ms": r_[4 + len(names)]} if not dbscan else {}))
+                          for j, r_ in enumerate(rows)]
+        if not dbscan:
+            extra["phase_ms"] = {nm: max(r_[4 + i] for r_ in rows) for i, nm in enumerate(names)}  # the slowest rank of each phase
         hp = torch.tensor([int(last.get("halo_points", 0))], dtype=torch.int64, device=dev)
         dist.all_reduce(hp, op=dist.ReduceOp.SUM)
         extra["halo_points"] = int(hp.item())

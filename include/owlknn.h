@@ -146,6 +146,9 @@ typedef struct {
                     tknnHaloSelect count pass was given boxes for ("interior"), searched in the own tree alone -- the call may
                     run on its own stream and host thread while the halo is exchanged and tknnSetHalo builds its tree.
                     2: the other ("boundary") queries, own + halo tree; rows and levels of a phase-1 call are kept.
+                    3: only the queries an earlier call with allow_unfinished left without a row (d_levels[row] == -1; d_levels
+                    required), from level 0 over own + halo tree; rows and levels of the others are kept -- the sharded
+                    driver's straggler rounds: the halo has been widened by the shell the next radius level needs.
                     Team kernels only (k <= 64). */
   int32_t *d_idx;
   float *d_dist;

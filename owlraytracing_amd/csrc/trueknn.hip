@@ -516,6 +516,12 @@ int64_t Engine::repair_exact(int k, float start_radius, const int32_t *d_levels,
   return (int64_t)h_counters_[0];
 }
 
+// tknnSolveOptions.phase == 3: per sorted slot, 1 for the queries an earlier call left unfinished (level -1 at their row)
+__global__ void __launch_bounds__(256) unfinished_mask_kernel(const int32_t *levels, const int32_t *prim_id, int64_t n, uint8_t *mask) {
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (t < n) mask[t] = levels[prim_id[t]] < 0 ? 1 : 0;
+}
+
 void Engine::solve(const SolveArgs &sa, int kernel, tknnSolveInfo *info, hipStream_t s) {
   if (kernel == TKNN_KERNEL_TEAM && !team_kernel_supports(sa.k))
     throw ArgError{TKNN_E_UNSUPPORTED, "the team kernels hold up to four neighbours per lane of a 16-lane team: k <= 64"};
@@ -537,9 +543,17 @@ void Engine::solve(const SolveArgs &sa, int kernel, tknnSolveInfo *info, hipStre
     throw ArgError{TKNN_E_UNSUPPORTED, "tknnSolveEx: per-query start radii and a halo tree do not combine (the halo is exchanged for ONE radius)"};
   if (sa.phase != 0) {
     if (kernel != TKNN_KERNEL_TEAM || bvh_.size() >= (1ll << 28))
-      throw ArgError{TKNN_E_UNSUPPORTED, "tknnSolveEx: phases (interior / boundary queries) are served by the team kernels only"};
-    if (!boundary_valid_)
+      throw ArgError{TKNN_E_UNSUPPORTED, "tknnSolveEx: phases (interior / boundary / unfinished queries) are served by the team kernels only"};
+    if (sa.phase == 3) {
+      // the queries an earlier call (allow_unfinished) left without a row: d_levels[row] < 0, marked per sorted slot
+      if (!sa.d_levels) throw ArgError{TKNN_E_ARG, "tknnSolveEx: phase 3 (unfinished queries only) needs the d_levels of the call that left them"};
+      const int64_t n = bvh_.size();
+      hipLaunchKernelGGL(unfinished_mask_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, sa.d_levels, bvh_.view().prim_id, n, boundary_);
+      OWLMI_HIP(hipGetLastError());
+      boundary_valid_ = false;  // (the marks of the last tknnHaloSelect are gone)
+    } else if (!boundary_valid_) {
       throw ArgError{TKNN_E_STATE, "tknnSolveEx: phase 1 / 2 need a tknnHaloSelect count pass since the last build (it marks the boundary queries)"};
+    }
   }
   struct HaloOff {  // phase 1 runs beside tknnSetHalo: it must not look at the halo tree
     bool &flag;
@@ -739,7 +753,7 @@ int tknnSolveEx(tknnEngine e, const tknnSolveOptions *options, tknnSolveInfo *in
     sa.allow_unfinished = options->allow_unfinished != 0;
     sa.phase = options->phase;
     sa.d_start_radii = options->d_start_radii;
-    if (sa.phase < 0 || sa.phase > 2) throw owlmi::ArgError{TKNN_E_ARG, "tknnSolveEx: phase must be 0 (all), 1 (interior) or 2 (boundary)"};
+    if (sa.phase < 0 || sa.phase > 3) throw owlmi::ArgError{TKNN_E_ARG, "tknnSolveEx: phase must be 0 (all), 1 (interior), 2 (boundary) or 3 (unfinished)"};
     if (info) std::memset(info, 0, sizeof(*info));
     e->impl.solve(sa, kernel, info, (hipStream_t)stream);
   });

@@ -2021,8 +2021,8 @@ bool Engine::solve_team(const SolveArgs &sa, tknnSolveInfo *info, hipStream_t s)
 
   // one launch instead of six fills (each costs a few microseconds of its own on the stream): done = 1,
   // tie = 0, all counters 0 except [9] (min hand-over level) = ~0, levels = -1
-  // (phase 2 completes the rows and levels a phase-1 call has begun: levels are preset once, by phase 0 or 1)
-  hipLaunchKernelGGL(team_prep_kernel, dim3(prop.multiProcessorCount * 4), dim3(256), 0, s, done_, tie_, n, counters_, sa.phase == 2 ? nullptr : sa.d_levels);
+  // (phases 2 and 3 complete the rows and levels an earlier call has begun: levels are preset once, by phase 0 or 1)
+  hipLaunchKernelGGL(team_prep_kernel, dim3(prop.multiProcessorCount * 4), dim3(256), 0, s, done_, tie_, n, counters_, sa.phase >= 2 ? nullptr : sa.d_levels);
   OWLMI_HIP(hipEventRecord(ev_a_, s));
   {
     void *kargs[] = {(void *)&a};

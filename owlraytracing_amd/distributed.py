@@ -64,6 +64,7 @@ class _Comm:
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
         self.staged = dist.get_backend(group) != "nccl"
+        self._caps = {}  # (tag, "in" | "out") -> rows per peer the next fixed-capacity exchange under that tag holds
 
     def _wire(self, t):
         return t.cpu() if self.staged and t.is_cuda else t
@@ -81,9 +82,71 @@ class _Comm:
         dist.all_gather(out, w, group=self.group)
         return torch.stack(out).to(t.device)
 
-    def exchange_rows(self, rows_per_peer, width, dtype, device):
+    def exchange_rows(self, rows_per_peer, width, dtype, device, tag=None):
         """all-to-all-v of 2-D row blocks: rows_per_peer[p] goes to rank p; returns the list of
-        blocks received (index = source rank).  Counts first, then one batched send/recv."""
+        blocks received (index = source rank).
+
+        Without ``tag``: counts first (an all-gather and a host round trip), then one batched
+        send/recv of exactly those rows.  With ``tag`` (the per-step halo exchange): ONE batched
+        send/recv of fixed-capacity messages whose first row carries the count -- the capacity of
+        every ordered pair is what both ends remember of the pair's last exchange under that tag
+        (x 1.25 + 64 rows); the first exchange under a tag, and any pair whose rows outgrow the
+        capacity (both ends see it: the sender by its rows, the receiver by the header), go
+        through exact-size messages once more.  Float32 headers hold counts < 2**24 exactly."""
+        world, me = self.world, self.rank
+        if tag is not None and dtype == torch.float32 and (tag, "in") in self._caps:
+            cap_in, cap_out = self._caps[(tag, "in")], self._caps[(tag, "out")]
+            recv = [None] * world
+            ops = []
+            msgs = []
+            for p in range(world):
+                if p == me:
+                    continue
+                rows = rows_per_peer[p]
+                m = torch.zeros((cap_out[p] + 1, width), dtype=dtype, device=rows.device)
+                m[0, 0] = float(len(rows) % (1 << 24))  # (two cells: float32 holds integers below 2**24 exactly)
+                m[0, 1] = float(len(rows) >> 24)
+                take = min(len(rows), cap_out[p])
+                if take:
+                    m[1:1 + take] = rows[:take]
+                msgs.append(m)
+                ops.append(dist.P2POp(dist.isend, self._wire(m), p, group=self.group))
+                recv[p] = torch.empty((cap_in[p] + 1, width), dtype=dtype, device="cpu" if self.staged else device)
+                ops.append(dist.P2POp(dist.irecv, recv[p], p, group=self.group))
+            if ops:
+                for req in dist.batch_isend_irecv(ops):
+                    req.wait()
+            peers = [p for p in range(world) if p != me]
+            heads = torch.stack([recv[p][0, :2] for p in peers]).tolist() if peers else []  # the step's one host round trip
+            counts_in = [0] * world
+            for p, h in zip(peers, heads):
+                counts_in[p] = int(h[0]) + (int(h[1]) << 24)
+            out = [None] * world
+            again = []  # pairs whose rows did not fit: exact-size messages, both ends know
+            for p in range(world):
+                if p == me:
+                    out[p] = rows_per_peer[p]
+                    continue
+                if counts_in[p] > cap_in[p]:
+                    again.append(("in", p))
+                else:
+                    out[p] = recv[p][1:1 + counts_in[p]].to(device)
+                if len(rows_per_peer[p]) > cap_out[p]:
+                    again.append(("out", p))
+            if again:
+                ops, late = [], {}
+                for kind, p in again:
+                    if kind == "out":
+                        ops.append(dist.P2POp(dist.isend, self._wire(rows_per_peer[p].contiguous()), p, group=self.group))
+                    else:
+                        late[p] = torch.empty((counts_in[p], width), dtype=dtype, device="cpu" if self.staged else device)
+                        ops.append(dist.P2POp(dist.irecv, late[p], p, group=self.group))
+                for req in dist.batch_isend_irecv(ops):
+                    req.wait()
+                for p, t in late.items():
+                    out[p] = t.to(device)
+            self._remember(tag, counts_in, [len(r) for r in rows_per_peer])
+            return out
         counts = torch.tensor([len(r) for r in rows_per_peer], dtype=torch.int64, device=device)
         counts_in = self.all_gather(counts)[:, self.rank].tolist()  # [src] rows coming from src
         recv = [torch.empty((int(c), width), dtype=dtype, device="cpu" if self.staged else device) for c in counts_in]
@@ -99,7 +162,16 @@ class _Comm:
             for req in dist.batch_isend_irecv(ops):
                 req.wait()
         recv[self.rank] = rows_per_peer[self.rank]
+        if tag is not None and dtype == torch.float32:
+            self._remember(tag, [int(c) for c in counts_in], [len(r) for r in rows_per_peer])
         return [r.to(device) for r in recv]
+
+    def _remember(self, tag, counts_in, counts_out):
+        """capacities of the next exchange under ``tag``: both ends of a pair derive the same number from the same count"""
+        grow = lambda c: int(c) + int(c) // 4 + 64  # noqa: E731
+        old_in, old_out = self._caps.get((tag, "in")), self._caps.get((tag, "out"))
+        self._caps[(tag, "in")] = [max(grow(c), old_in[p] if old_in else 0) for p, c in enumerate(counts_in)]
+        self._caps[(tag, "out")] = [max(grow(c), old_out[p] if old_out else 0) for p, c in enumerate(counts_out)]
 
 
 class ShardedTrueKNN:
@@ -285,6 +357,22 @@ class ShardedTrueKNN:
         hi = torch.where(hi.double() < hi64, torch.nextafter(hi, torch.full_like(hi, float("inf"))), hi)
         return lo, hi
 
+    @staticmethod
+    def _merge_infos(a, b, levels_counted_twice):
+        """info of two engine calls that together are one solve (interior + boundary queries; a solve and the re-solve of
+        the queries it left unfinished, whose ``levels_counted_twice`` active levels the first call has counted already)"""
+        merged = dict(b)
+        for key in ("total_intersections", "total_active_rounds", "node_tests", "point_tests", "tie_rows", "tie_rows_left", "solve_ms", "tie_ms"):
+            merged[key] = a[key] + b[key]
+        merged["total_active_rounds"] -= levels_counted_twice
+        merged["unfinished"] = b["unfinished"] if levels_counted_twice else a["unfinished"] + b["unfinished"]
+        merged["rounds"] = max(a["rounds"], b["rounds"])
+        merged["final_radius"] = max(a["final_radius"], b["final_radius"])
+        merged["dominant_kernel_launches"] = a["dominant_kernel_launches"] + b["dominant_kernel_launches"]
+        merged["dominant_kernel_ms"] = ((a["dominant_kernel_ms"] * a["dominant_kernel_launches"] + b["dominant_kernel_ms"] * b["dominant_kernel_launches"])
+                                        / max(merged["dominant_kernel_launches"], 1))
+        return merged
+
     def solve(self, k, start_radius, max_rounds=64, want_fb=False):
         comm, dev = self.comm, self.device
         r0 = np.float32(start_radius)
@@ -310,6 +398,10 @@ class ShardedTrueKNN:
 
         first = True
         overlapped = False
+        halo = None                         # every foreign row received so far (the halo tree's points)
+        sent = [None] * comm.world          # ids of my rows each peer holds already
+        round_halo = []                     # rows received per exchange
+        res = None
         while True:
             halo_radius = np.float32(r0)
             for _ in range(level_cap):
@@ -317,6 +409,17 @@ class ShardedTrueKNN:
             t = time.perf_counter()
             self._boundary_marked = False
             blocks = self._halo_blocks(halo_radius)
+            if not first:
+                # a straggler round: the peers hold what the smaller radius selected -- only the SHELL between the two
+                # radii travels ("only the incremental shell (r_{t-1}, r_t] need be sent after round 1")
+                for p in range(comm.world):
+                    if p != comm.rank and len(blocks[p]) and sent[p] is not None and len(sent[p]):
+                        ids_p = blocks[p][:, 3].contiguous().view(torch.int32)
+                        blocks[p] = blocks[p][~torch.isin(ids_p, sent[p])]
+            for p in range(comm.world):
+                if p != comm.rank and len(blocks[p]):
+                    ids_p = blocks[p][:, 3].contiguous().view(torch.int32)
+                    sent[p] = ids_p if sent[p] is None else torch.cat([sent[p], ids_p])
             t = lap("select", t)
             two_phases = (first and self.overlap and self._boundary_marked and getattr(self.engine, "supports_phases", False)
                           and dev.type == "cuda" and k <= 64 and self.kernel in (_lib.KERNEL_AUTO, _lib.KERNEL_TEAM))
@@ -351,11 +454,15 @@ class ShardedTrueKNN:
                 t_int = time.perf_counter()
                 worker.start()
             try:
-                got = comm.exchange_rows(blocks, 4, torch.float32, dev)
+                # (tagged: fixed-capacity messages with the count in their first row -- one exchange, one host round
+                # trip -- once a first exchange at this radius level has told both ends of every pair how much travels)
+                got = comm.exchange_rows(blocks, 4, torch.float32, dev, tag=("halo", level_cap, first))
                 got[comm.rank] = got[comm.rank][:0]
-                halo = torch.cat(got, dim=0)
+                new_rows = torch.cat(got, dim=0)
                 t = lap("exchange", t)
                 exchanges += 1
+                round_halo.append(int(len(new_rows)))
+                halo = new_rows if halo is None else torch.cat([halo, new_rows], dim=0)
                 halo_points = len(halo)
                 self.engine.set_halo(halo[:, :3].contiguous(), halo[:, 3].contiguous().view(torch.int32))
                 t = lap("halo_build", t)
@@ -370,19 +477,15 @@ class ShardedTrueKNN:
                 t = time.perf_counter()
                 # boundary queries: own + halo tree, rows and levels of the interior queries stay
                 res = self.engine.solve(k, float(r0), out={kk: v for kk, v in interior["res"].items() if kk != "info"}, phase=2, **solve_kw)
-                a, b = interior["res"]["info"], res["info"]
-                merged = dict(b)
-                for key in ("total_intersections", "total_active_rounds", "node_tests", "point_tests", "unfinished", "tie_rows",
-                            "tie_rows_left", "solve_ms", "tie_ms"):
-                    merged[key] = a[key] + b[key]
-                merged["rounds"] = max(a["rounds"], b["rounds"])
-                merged["final_radius"] = max(a["final_radius"], b["final_radius"])
-                merged["dominant_kernel_launches"] = a["dominant_kernel_launches"] + b["dominant_kernel_launches"]
-                merged["dominant_kernel_ms"] = (a["dominant_kernel_ms"] * a["dominant_kernel_launches"] + b["dominant_kernel_ms"] * b["dominant_kernel_launches"]) / max(merged["dominant_kernel_launches"], 1)
-                res["info"] = merged
-            else:
+                res["info"] = self._merge_infos(interior["res"]["info"], res["info"], 0)
+            elif first:
                 # levels 0..level_cap are exact with this halo; stop there and see who is left
                 res = self.engine.solve(k, float(r0), **solve_kw)
+            else:
+                # only the queries the rounds so far left unfinished, over own + widened halo tree; every other row stays
+                before = res["info"]
+                res = self.engine.solve(k, float(r0), out={kk: v for kk, v in res.items() if kk != "info"}, phase=3, **solve_kw)
+                res["info"] = self._merge_infos(before, res["info"], int(before["unfinished"]) * level_cap)
             t = lap("solve", t)
             first = False
             left = torch.tensor([int(res["info"]["unfinished"])], dtype=torch.int64, device=dev)
@@ -393,13 +496,14 @@ class ShardedTrueKNN:
                 break
             if level_cap + 1 >= max_rounds:
                 raise _lib.TknnError(-4, "max_rounds reached with unfinished queries")
-            level_cap += 1  # stragglers need the next radius level: widen the halo and solve again
+            level_cap += 1  # stragglers need the next radius level: widen the halo by its shell and solve them again
         rounds = torch.tensor([int(res["info"]["rounds"])], dtype=torch.int64, device=dev)
         comm.all_reduce(rounds, dist.ReduceOp.MAX)
         info = dict(res["info"])
         info["rounds"] = int(rounds.item())
         info["halo_exchanges"] = exchanges
         info["halo_points"] = halo_points
+        info["halo_points_by_exchange"] = round_halo  # the first exchange's halo, then the shells of the straggler rounds
         info["halo_levels"] = level_cap
         info["overlapped"] = bool(overlapped)
         if profile:

@@ -34,17 +34,31 @@ class CheckerEngine:
         else:
             self.halo = (points.cpu().numpy(), ids.cpu().numpy())
 
-    def solve(self, k, start_radius, kernel=0, max_rounds=64, want_fb=False, want_levels=False, allow_unfinished=False, out=None):
+    def solve(self, k, start_radius, kernel=0, max_rounds=64, want_fb=False, want_levels=False, allow_unfinished=False, out=None, phase=0):
         from oracle.trueknn_numpy import trueknn_numpy
         xyz = np.concatenate([self.pts, self.halo[0]])
         ids = np.concatenate([self.ids, self.halo[1]]).astype(np.int64)
         r = trueknn_numpy(xyz, k, start_radius, max_rounds=max_rounds, query_ids=np.arange(self.n),
                           stop_quietly=allow_unfinished, ids=ids)
         lev = r["level"][: self.n]
+        if phase == 3:
+            # tknnSolveOptions.phase = 3: only the rows an earlier call left unfinished (level -1) are solved; the others stay
+            todo = out["levels"].numpy() < 0
+            idx, dst, isect, levels = out["idx"].numpy(), out["dist"].numpy(), out["intersections"].numpy(), out["levels"].numpy()
+            done_now = todo & (lev >= 0)
+            idx[done_now], dst[done_now] = r["idx"][: self.n][done_now].astype(np.int32), r["dist"][: self.n][done_now]
+            isect[done_now], levels[done_now] = r["intersections"][: self.n][done_now], lev[done_now].astype(np.int32)
+            info = {"rounds": int(lev[done_now].max()) + 1 if done_now.any() else 0, "unfinished": int((todo & (lev < 0)).sum()),
+                    "total_intersections": int(r["intersections"][: self.n][done_now].sum()), "kernel_used": 0,
+                    "dominant_kernel_ms": 0.0, "dominant_kernel_launches": 1, "node_tests": 0, "point_tests": 0,
+                    "total_active_rounds": 0, "solve_ms": 0.0, "final_radius": r["final_radius"], "list_capacity": k,
+                    "tie_rows": 0, "tie_rows_left": 0, "tie_ms": 0.0}
+            return {"idx": out["idx"], "dist": out["dist"], "intersections": out["intersections"], "levels": out["levels"], "info": info}
         info = {"rounds": int(lev.max()) + 1 if (lev >= 0).any() else r["rounds"], "unfinished": int((lev < 0).sum()),
                 "total_intersections": int(r["intersections"][: self.n][lev >= 0].sum()), "kernel_used": 0,
                 "dominant_kernel_ms": 0.0, "dominant_kernel_launches": 1, "node_tests": 0, "point_tests": 0,
-                "total_active_rounds": 0, "solve_ms": 0.0, "final_radius": r["final_radius"], "list_capacity": k}
+                "total_active_rounds": 0, "solve_ms": 0.0, "final_radius": r["final_radius"], "list_capacity": k,
+                "tie_rows": 0, "tie_rows_left": 0, "tie_ms": 0.0}
         return {"idx": torch.from_numpy(r["idx"][: self.n].astype(np.int32)),
                 "dist": torch.from_numpy(r["dist"][: self.n]),
                 "intersections": torch.from_numpy(r["intersections"][: self.n]),
@@ -142,7 +156,8 @@ def main():
     gids, idx, dst, isect = solver.gather_rows()
     if rank == 0:
         np.savez(out, gids=gids, idx=idx, dist=dst, isect=isect, rounds=info["rounds"],
-                 exchanges=info["halo_exchanges"], halo_points=info["halo_points"], tile=len(solver.points))
+                 exchanges=info["halo_exchanges"], halo_points=info["halo_points"], tile=len(solver.points),
+                 halo_by_exchange=np.asarray(info["halo_points_by_exchange"], np.int64), total_isect=info["total_intersections"])
     dist.barrier()
     dist.destroy_process_group()
 

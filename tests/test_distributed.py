@@ -78,6 +78,73 @@ def test_stragglers_force_a_wider_halo(tmp_path):
     assert int(got["exchanges"]) > 1
 
 
+def test_straggler_rounds_send_the_shell_and_solve_only_the_stragglers(tmp_path):
+    """a widening round re-sent the whole halo at the doubled radius and re-solved every query.  Now only
+    the points between the two radii travel (the shell) and only the unfinished queries are solved again
+    (tknnSolveOptions.phase = 3): with HALO_LEVELS=0 on the clustered set every level is a round of its own -- rows,
+    intersection counts and rounds still equal the single-process result, each later exchange carries the shell alone
+    (what the peers hold is never sent twice: the shells add up to exactly the halo the final radius selects), and
+    the sum of the per-query intersection counts the driver reports is the reference's."""
+    n, k = 2500, 4
+    got = _run("checker", 3, n, k, "clustered", tmp_path, 29634, {"HALO_LEVELS": "0", "START_RADIUS": "0.01"})
+    _check(got, "clustered", n, k, r0=0.01)
+    by = got["halo_by_exchange"]
+    assert int(got["exchanges"]) == len(by) >= 3
+    assert int(by.sum()) == int(got["halo_points"])  # rank 0's halo tree = the first halo + the shells, nothing twice
+    # a whole re-send would carry at least the previous halo again: every shell is smaller than what is held already
+    assert all(int(by[j]) < int(by[:j].sum()) for j in range(2, len(by)))
+    from dist_worker import make_points
+    ref = oracle.trueknn(make_points("clustered", n), k, 0.01)
+    assert int(got["isect"].sum()) == int(ref["intersections"].sum())
+
+
+def test_fixed_capacity_exchange_carries_counts_in_the_first_row(tmp_path):
+    """_Comm.exchange_rows with a tag: after a first (counts-first) exchange under the tag, messages have a fixed capacity
+    and their first row holds the count -- one exchange instead of two; a pair that outgrows its capacity falls back to
+    exact-size messages.  Two gloo ranks trade row blocks of changing sizes; every block arrives intact."""
+    script = tmp_path / "xchg.py"
+    script.write_text("""
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, %r)
+from owlraytracing_amd.distributed import _Comm
+dist.init_process_group("gloo")
+c = _Comm()
+r, w = c.rank, c.world
+dev = torch.device("cpu")
+def block(src, dst, m, step):
+    return (torch.arange(m * 4, dtype=torch.float32).reshape(m, 4) + 1000.0 * src + 10.0 * dst + 0.25 * step)
+sizes = [(5, 7), (5, 7), (6, 3), (40, 2), (0, 0), (300, 300)]   # rows 0 -> 1, rows 1 -> 0 per step: same, shrinking, outgrowing, empty
+for step, (a, b) in enumerate(sizes):
+    m_out = [0, 0]
+    m_out[1 - r] = a if r == 0 else b
+    blocks = [block(r, p, m_out[p], step) for p in range(w)]
+    got = c.exchange_rows(blocks, 4, torch.float32, dev, tag="t")
+    m_in = b if r == 0 else a
+    want = block(1 - r, r, m_in, step)
+    assert got[1 - r].shape == want.shape and torch.equal(got[1 - r], want), (step, r, got[1 - r].shape, want.shape)
+    if step >= 1:
+        assert ("t", "in") in c._caps
+print("rank %%d ok caps %%s" %% (r, c._caps[("t", "in")]))
+dist.destroy_process_group()
+""" % ROOT)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29637", str(script)]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    assert r.stdout.count(" ok caps ") == 2
+
+
+@pytest.mark.gpu
+def test_straggler_rounds_with_the_hip_engine(tmp_path):
+    """The same with the real engine (tknnSolveOptions.phase = 3 over own + widened halo tree), three ranks sharing the GPU."""
+    n, k = 150_000, 8
+    got = _run("hip", 3, n, k, "clustered", tmp_path, 29648, {"HALO_LEVELS": "0", "START_RADIUS": "0.001"})
+    _check(got, "clustered", n, k, r0=0.001)
+    by = got["halo_by_exchange"]
+    assert len(by) >= 3 and int(by.sum()) == int(got["halo_points"])
+
+
 @pytest.mark.gpu
 def test_two_ranks_sharing_one_gpu_with_the_hip_engine(tmp_path):
     """Real engine (ids, halo tree, allow_unfinished) under the sharded driver; messages host-staged
