@@ -477,9 +477,11 @@ __device__ __forceinline__ void team_pass(const TeamArgs &a, const TeamLds &L, i
     // plain VALU instruction on gfx950) and every wave-mask operation a slot of the CU's one scalar
     // pipe, which this kernel fills as much as the vector pipes (scripts/microbench/issue_rate.hip).
     auto in_box = [&](const LbvhPoint &p, float t, float radius, float below, float upto) -> unsigned long long {
-      unsigned long long in_m = __ballot(t <= radius);
-      if (__builtin_expect(__ballot(fabsf(t - radius) <= t_mg) != 0ull, 0))
-        in_m = __ballot(t <= below) | (__ballot(t <= upto) & __ballot(knn_in_box(p.x, p.y, p.z, radius, t_qx, t_qy, t_qz)));
+      // certainly in | possibly in: two compares against the band's edges (no subtraction); they differ for a point in a
+      // thousand blocks, and only then does the literal test run
+      unsigned long long in_m = __ballot(t <= below);
+      const unsigned long long maybe = __ballot(t <= upto);
+      if (__builtin_expect(maybe != in_m, 0)) in_m |= maybe & __ballot(knn_in_box(p.x, p.y, p.z, radius, t_qx, t_qy, t_qz));
       return in_m;
     };
     auto process = [&](const LbvhPoint &p, bool own_block = false) {

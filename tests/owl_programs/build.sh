@@ -11,4 +11,6 @@ g++ -O2 -std=c++17 -Wall -I"$root/include" -I"$root/include/owl_shims" -I/opt/ro
     "$here/owl_host_driver.cpp" -o "$out/owl_host_driver" \
     -L"$root/owlraytracing_amd" -lowl_mi355x -L/opt/rocm/lib -lamdhip64 \
     -Wl,-rpath,"$root/owlraytracing_amd" -Wl,-rpath,'$ORIGIN/../../owlraytracing_amd' -Wl,-rpath,/opt/rocm/lib
+# the RT-DBSCAN application on the OWL API (samples/s02-rtdbscan: host code + device programs of this repository)
+bash "$root/samples/s02-rtdbscan/build.sh" > /dev/null
 echo "built $out"

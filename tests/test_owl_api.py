@@ -195,6 +195,37 @@ def test_managed_buffer_pointer_held_across_launches(tmp_path, policy):
 
 
 @pytest.mark.gpu
+def test_rtdbscan_sample_on_the_program_model(tmp_path):
+    """samples/s02-rtdbscan -- RT-DBSCAN written as an OWL application (host code on owl* only; ONE intersection program
+    that counts neighbours, unites core points with atomics in a union-find and assigns border points; two launches
+    without rays for the flags and the roots): the boundary BASELINE's north_star names carries the second workload too.
+    Labels and core flags equal the CPU spec's on a 3-D mixture and on a 2-D set with duplicates read as dim = 2."""
+    exe = os.path.join(ROOT, "build", "owl_tests", "sample02-rtdbscan")
+    if not os.path.exists(exe):
+        pytest.fail("build/owl_tests/sample02-rtdbscan is not built (__graft_entry__.build() -> tests/owl_programs/build.sh)")
+    import oracle
+    from owlraytracing_amd import datasets
+    cases = [("mixture3d", datasets.gaussian_mixture3d(20_000, components=8, sigma=0.03, seed=11), 3, 0.012, 5),
+             ("taxi2d", datasets.taxi_like2d(15_000, components=10, seed=12), 2, 0.004, 4)]
+    for name, pts, dim, eps, min_pts in cases:
+        csv = tmp_path / (name + ".csv")
+        datasets.write_csv_points(str(csv), pts)
+        # the sample parses the text with operator>>: the oracle must see the values it read
+        seen = datasets.read_csv_points(str(csv), len(pts), dim)
+        eps32 = float(np.float32(eps))
+        ref = oracle.dbscan(datasets.pad_to_3d(seen), eps32, min_pts)
+        out = tmp_path / (name + ".bin")
+        r = subprocess.run([exe, str(csv), str(len(pts)), str(dim), repr(eps32), str(min_pts), str(out)], capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout + r.stderr
+        raw = out.read_bytes()
+        labels = np.frombuffer(raw, np.int32, len(pts), 0)
+        core = np.frombuffer(raw, np.uint8, len(pts), 4 * len(pts)).astype(bool)
+        assert np.array_equal(core, ref["core"].astype(bool)), name
+        assert np.array_equal(labels, ref["labels"]), name
+        assert "clusters=%d " % ref["clusters"] in r.stdout, r.stdout
+
+
+@pytest.mark.gpu
 def test_unchanged_reference_sample_runs(tmp_path):
     """samples/s01-trueknn (hostCode.cpp + deviceCode.cu, unchanged) linked against libowl_mi355x."""
     if not os.path.exists(REF_SAMPLE):
