@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """Side measurements for DESIGN.md (not the contract bench): non-uniform TrueKNN inputs, RT-DBSCAN at
-BASELINE config 3 scale, and the unchanged reference sample through the OWL program model."""
+BASELINE config 3 scale, and the unchanged reference sample through the OWL program model.  The two runs README / DESIGN
+quote a time for -- BASELINE config 4's 100 M-point set and config 5's 50 M-point set on one GPU -- assert the structure of
+what they time (check_rows; noise / cluster bookkeeping); their comparison with the CPU checker is in the GPU test suite."""
 import json
 import os
 import subprocess
@@ -19,9 +21,30 @@ from owlraytracing_amd.trueknn import TrueKNN  # noqa: E402
 out = {}
 
 
-def timed_solve(name, pts, k, r0, kernels=(3, 2, 1)):
+def check_rows(pts_dev, r, n, k):
+    """What a timed solve must satisfy before its time is recorded (no checker here -- scripts never import oracle/; the
+    comparisons with the CPU checker at these sizes are tests/test_trueknn_gpu.py::test_full_size_*): every row without its
+    own point, indices in range, distances ascending, intersection counts adding up, and the distances of a 2 M-row slice
+    recomputed in fp64 from the indices."""
+    idx, dist, isect, info = r["idx"], r["dist"], r["intersections"], r["info"]
+    assert info["unfinished"] == 0 and info["tie_rows_left"] == 0
+    assert int(isect.sum()) == info["total_intersections"]
+    step = 10_000_000
+    for lo in range(0, n, step):
+        hi = min(n, lo + step)
+        i, d = idx[lo:hi], dist[lo:hi]
+        ar = torch.arange(lo, hi, device=i.device, dtype=torch.int32)[:, None]
+        assert bool((i != ar).all()) and bool((i >= 0).all()) and bool((i < n).all())
+        assert bool((d[:, 1:] >= d[:, :-1]).all())
+    lo, hi = max(0, n // 2 - 1_000_000), min(n, n // 2 + 1_000_000)
+    d64 = (pts_dev[idx[lo:hi].long()].double() - pts_dev[lo:hi, None, :].double()).norm(dim=2)
+    assert float((d64 - dist[lo:hi].double()).abs().max()) < 1e-6
+
+
+def timed_solve(name, pts, k, r0, kernels=(3, 2, 1), check=False):
     eng = TrueKNN()
-    b = eng.build(torch.from_numpy(pts).cuda())
+    pts_dev = torch.from_numpy(pts).cuda()
+    b = eng.build(pts_dev)
     res = {"n": len(pts), "k": k, "r0": r0, "build_ms": b["build_ms"]}
     for kern in kernels:
         best = None
@@ -32,8 +55,10 @@ def timed_solve(name, pts, k, r0, kernels=(3, 2, 1)):
             torch.cuda.synchronize()
             w = (time.perf_counter() - t) * 1e3
             best = w if best is None else min(best, w)
+        if check:
+            check_rows(pts_dev, r, len(pts), k)
         res["kernel_%d" % kern] = {"wall_ms": best, "rounds": r["info"]["rounds"], "used": r["info"]["kernel_used"],
-                                   "isect_per_query": r["info"]["total_intersections"] / len(pts)}
+                                   "isect_per_query": r["info"]["total_intersections"] / len(pts), "rows_checked": bool(check)}
         print(name, kern, res["kernel_%d" % kern], flush=True)
     eng.close()
     out[name] = res
@@ -49,7 +74,7 @@ def main():
     if "sizes" in which:  # config 4's whole 100 M-point set on ONE GPU
         for n in (50_000_000, 100_000_000):
             pts = datasets.uniform3d_counter(0, n, seed=0)
-            timed_solve("trueknn_uniform3d_%dM_k10" % (n // 1_000_000), pts, 10, datasets.start_radius(n, 10), kernels=(3,))
+            timed_solve("trueknn_uniform3d_%dM_k10" % (n // 1_000_000), pts, 10, datasets.start_radius(n, 10), kernels=(3,), check=True)
             del pts
     if "dbscan_auto" in which:  # config 5's point set (50 M heavy-tailed 2-D points, 5 % duplicates) on ONE GPU, eps auto-grown
         pts = datasets.pad_to_3d(datasets.taxi_like2d(50_000_000, components=256, seed=2))
@@ -62,6 +87,10 @@ def main():
             torch.cuda.synchronize()
             w = (time.perf_counter() - t) * 1e3
             i = r["info"]
+            # what the timed call must satisfy (the comparison with the CPU spec: tests/test_dbscan.py::test_config5_set_full_size_auto_eps)
+            lab, core = r["labels"], r["core"]
+            assert i["noise"] == int((lab < 0).sum()) <= int(max_noise * len(pts))
+            assert i["clusters"] == int(lab.max()) + 1 and bool((lab[core] >= 0).all())
             out["dbscan_auto_taxi2d_50M_minpts4_eps0_%g_noise_%g" % (eps0, max_noise)] = {
                 "wall_ms": w, "build_ms": b["build_ms"], "rounds": i["rounds"], "eps": i["eps"], "noise": i["noise"], "clusters": i["clusters"],
                 "probe_rounds_ms": i["probe_ms"], "final_clustering_ms": i["solve_ms"]}
