@@ -90,7 +90,7 @@ struct TeamLayout {
   // prefetches one group of four past the end of a list rounded up to whole groups)
   static constexpr int kEntStride = kMaxPerQuery + 4;
   static constexpr int kLdsEnt = 4 * kEntStride * 4;
-  static constexpr int kLdsCand = NREG == 1 ? 4 * kCandCap * 8 + 16 : 0;
+  static constexpr int kLdsCand = NREG == 1 ? 4 * kCandCap * 8 : 0;
   static constexpr int kOffMask = kLdsQrec + kLdsBlk;
   static constexpr int kOffShared = kOffMask + kLdsMask;
   static constexpr int kOffEnt = kOffShared + kLdsSharedPadded;
@@ -269,7 +269,6 @@ struct TeamLds {
   int32_t *qlist;     // compact list of the queries this pass serves
   int32_t *ent;       // [4][kEntStride] per team: resolved block entries of its query, in visit order
   unsigned long long *cand;  // [4][kCandCap] per team: keys waiting to be merged into its list
-  uint32_t *cand_n;          // [4] how many
 };
 
 // Can two candidates of one query at the same fp32 distance d have become candidates in DIFFERENT
@@ -439,9 +438,13 @@ __device__ __forceinline__ void team_pass(const TeamArgs &a, const TeamLds &L, i
     // whatever the number of candidates, no LDS crossbar, no scalar mask arithmetic.  Between merges the
     // gate is the last merge's k-th distance: looser than it could be, never wrong.
     bool dirty = false;  // wave-uniform: some team has buffered candidates
+    // how many wait in my team's buffer (the same in its sixteen lanes).  In a register, advanced by population counts of the
+    // candidate mask: the slot of a candidate used to come from an LDS atomic -- a round trip through the LDS pipe in the
+    // middle of every block step that had a candidate, in a kernel that is bound by the latency of such chains
+    uint32_t fill_n = 0;
     auto merge_buffer = [&]() {
       t_wave_sync();
-      const uint32_t fill = L.cand_n[team];
+      const uint32_t fill = fill_n;
 #pragma unroll
       for (int row = 0; row < kCandCap / 16; row++) {
         if (row > 0 && __ballot(fill > 16u * (uint32_t)row) == 0ull) break;
@@ -464,9 +467,8 @@ __device__ __forceinline__ void team_pass(const TeamArgs &a, const TeamLds &L, i
         exchange(bd[0], bi[0], t_dpp<0x4e>(bd[0]), t_dpp<0x4e>(bi[0]), up2);
         exchange(bd[0], bi[0], t_dpp<0xb1>(bd[0]), t_dpp<0xb1>(bi[0]), up1);
       }
-      t_wave_sync();
-      if (tl == 0) L.cand_n[team] = 0u;
-      t_wave_sync();
+      t_wave_sync();  // (the rows are read: the next candidates may overwrite them)
+      fill_n = 0;
       dirty = false;
       tau2 = knn_gate_from_worst(kth_dist());
     };
@@ -503,15 +505,14 @@ __device__ __forceinline__ void team_pass(const TeamArgs &a, const TeamLds &L, i
             if (TKNN_DIAG_BUILD && (a.diag & 16) && lane == 0) atomicAdd(&a.counters[26], (unsigned long long)__popcll(pm));
             // my candidate into the team's buffer; a full row of sixteen is merged at once (a block
             // adds at most sixteen to at most fifteen: the buffer holds 32)
-            bool row_full = false;
-            if ((pm >> lane) & 1ull) {
+            const uint32_t mine16 = (uint32_t)(pm >> (team << 4)) & 0xffffu;  // my team's lanes with a candidate
+            if ((mine16 >> tl) & 1u) {
               const unsigned long long key = ((unsigned long long)__float_as_uint(d2) << 32) | (uint32_t)p.id;  // (the root: merge_buffer)
-              const uint32_t slot = __hip_atomic_fetch_add(&L.cand_n[team], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-              L.cand[team * kCandCap + slot] = key;
-              row_full = slot >= 15u;
+              L.cand[team * kCandCap + fill_n + __popc(mine16 & ((1u << tl) - 1u))] = key;
             }
+            fill_n += __popc(mine16);
             dirty = true;
-            if (__ballot(row_full) != 0ull) {
+            if (__ballot(fill_n >= 16u) != 0ull) {
               if (TKNN_DIAG_BUILD && (a.diag & 16) && lane == 0) atomicAdd(&a.counters[27], 1ull);
               merge_buffer();
             }
@@ -633,7 +634,7 @@ __device__ __forceinline__ void team_pass(const TeamArgs &a, const TeamLds &L, i
       b3 = fetch(g.w);
       // a tighter gate for the next group as soon as a handful of candidates wait (the first groups, whose
       // blocks lie next to the query, bring most of them)
-      if (SELECT && NREG == 1 && dirty && __ballot(L.cand_n[team] >= (uint32_t)TKNN_MERGE_AT) != 0ull) {
+      if (SELECT && NREG == 1 && dirty && __ballot(fill_n >= (uint32_t)TKNN_MERGE_AT) != 0ull) {
         if (TKNN_DIAG_BUILD && (a.diag & 16) && lane == 0) atomicAdd(&a.counters[27], 1ull);
         merge_buffer();
       }
@@ -736,8 +737,6 @@ __global__ void __launch_bounds__(kTeamBlock) __attribute__((amdgpu_waves_per_eu
   int32_t *stack = (int32_t *)(base + Lay::kOffShared);  // shares the counts / query list region
   int32_t *ent = (int32_t *)(base + Lay::kOffEnt);
   unsigned long long *cand = (unsigned long long *)(base + Lay::kOffCand);  // (k <= 16 only: zero bytes otherwise, never touched)
-  uint32_t *cand_n = (uint32_t *)(base + Lay::kOffCand + 4 * kCandCap * 8);
-  if (NREG == 1 && lane < 4) cand_n[lane] = 0u;
 
   const LbvhPoint *own_pts = a.bvh.points + tl, *halo_pts = a.halo.points ? a.halo.points + tl : a.bvh.points + tl;
   unsigned long long my_isect_sum = 0, my_levels = 0, my_unfinished = 0, wave_node_tests = 0, wave_point_tests = 0;
@@ -806,7 +805,6 @@ __global__ void __launch_bounds__(kTeamBlock) __attribute__((amdgpu_waves_per_eu
     L.qlist = qlist;
     L.ent = ent;
     L.cand = cand;
-    L.cand_n = cand_n;
 
     // One gather may serve MORE than the step it is made for: when the queries are unlikely all to finish inside the step
     // (levels level .. level+m-1), the walk is made at the radius of the level after it ("extension"), and every block a
