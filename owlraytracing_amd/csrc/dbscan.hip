@@ -63,6 +63,7 @@ struct DbArgs {
   int chunk;  // packets per chunk dealt to an XCD (db_group_union_kernel)
   int scan_budget;  // steps the quick scan of a probe may take before the subtrees are asked (db_group_union_kernel)
   float reach, near_lo2, near_hi2;  // this pass of db_group_union_kernel: groups whose nearest faces are near_lo2 < d^2 <= near_hi2 apart, reach >= sqrt(near_hi2)
+  unsigned long long *diag_out;  // diagnostic library, TKNN_DB_DIAG & 512: the group-union kernel's wave time by part ([0] loads [1] tests [2] settles [3] pushes [4] packet set-up, s_memtime ticks) and [5] rounds [6] settles [7] packets
   int diag;  // TKNN_DB_DIAG, diagnostic library only (results are wrong when set): 1 = no probes, 2 = no unions between groups, 4 = none inside groups, 8 = walk lengths on stderr, 16 = report a stack overflow (the result is right: the call falls back), 32 = probes by scanning only (the result is right)
 };
 
@@ -621,8 +622,20 @@ __global__ void __launch_bounds__(kDbUnionBlock) __attribute__((amdgpu_waves_per
     return 0;
   };
   int waiting = 0;
+  [[maybe_unused]] unsigned long long tm[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tm_mark = 0;
+  const bool timing = TKNN_DIAG_BUILD && (a.diag & 512);
+#define DB_LAP(i)                                                  \
+  do {                                                             \
+    if (timing) {                                                  \
+      const unsigned long long now_ = __builtin_amdgcn_s_memtime(); \
+      tm[i] += now_ - tm_mark;                                     \
+      tm_mark = now_;                                              \
+    }                                                              \
+  } while (0)
   // what the lanes have collected: two rounds of loads for all of it, then one group after the other
   auto settle = [&]() {
+    DB_LAP(1);
+    if (timing) tm[6]++;
     int32_t b_core[kDbBuf], b_last[kDbBuf], par[kDbBuf];
 #pragma unroll
     for (int w = 0; w < kDbBuf; w++) {
@@ -677,7 +690,9 @@ __global__ void __launch_bounds__(kDbUnionBlock) __attribute__((amdgpu_waves_per
       }
     }
     waiting = 0;
+    DB_LAP(2);
   };
+  if (timing) tm_mark = __builtin_amdgcn_s_memtime();
   for (;;) {
     // ---- take a packet.  Each XCD has its own L2: the list is dealt to the XCDs in chunks of packets, a wave takes from
     // the chunks of the XCD it runs on and from the others' when those are used up.
@@ -727,7 +742,10 @@ __global__ void __launch_bounds__(kDbUnionBlock) __attribute__((amdgpu_waves_per
     int top = 1;
     if (lane == 0) stack[0] = bvh.root;
     db_wave_sync();
+    DB_LAP(4);
+    if (timing) tm[7]++;
     while (top > 0) {
+      if (timing) tm[5]++;
       // lanes = nodes: pop, load, stage
       const int width = top > kDbStack - 256 ? 1 : 64;
       const int n_pop = min(top, width);
@@ -755,6 +773,7 @@ __global__ void __launch_bounds__(kDbUnionBlock) __attribute__((amdgpu_waves_per
       // nodes nothing can come of: past the packet's last use, or a leaf that is not core
       const unsigned long long m_live = __ballot(valid && any_core && b_last > low), m_tight = __ballot(tight);
       db_wave_sync();
+      DB_LAP(0);
       // lanes = groups
       unsigned long long m_open = 0ull;  // nodes some group reaches and that are not tight
       for (unsigned long long todo = m_live; todo;) {
@@ -779,6 +798,7 @@ __global__ void __launch_bounds__(kDbUnionBlock) __attribute__((amdgpu_waves_per
         }
         if (__ballot(waiting == kDbBuf) != 0ull) settle();
       }
+      DB_LAP(1);
       // lanes = nodes: children (the left one only if it reaches past the packet's earliest group)
       const bool kids = (m_open >> lane) & 1ull;
       const bool left_too = kids && split > low;
@@ -793,9 +813,13 @@ __global__ void __launch_bounds__(kDbUnionBlock) __attribute__((amdgpu_waves_per
       if (kids) stack[top + n_left + __popcll(m_open & below)] = b_last == split + 1 ? ~(split + 1) : split + 1;  // lbvh_right_ref
       top += n_left + n_right;
       db_wave_sync();
+      DB_LAP(3);
     }
     if (__ballot(waiting > 0) != 0ull) settle();
   }
+  if (timing && lane == 0)
+    for (int i = 0; i < 8; i++) atomicAdd(&a.diag_out[i], tm[i]);
+#undef DB_LAP
   if (a.diag & 8) {  // [6] most walk steps of a wave, [7] their sum
     if (lane == 0) {
       atomicMax(&a.stats[6], (unsigned long long)node_tests);
@@ -1108,6 +1132,7 @@ void Engine::dbscan(float eps, int min_pts, int32_t *d_labels, uint8_t *d_core, 
   // every point's group, for the union pass; kept in the caller's label array, which is written last
   a.group_of = core_label || per_point ? nullptr : d_labels;
   const unsigned blocks = (unsigned)((n + kDbBlock - 1) / kDbBlock);
+  a.diag_out = counters_ + 20;
   a.stats = counters_ + kCounters;  // striped (db_add_stats); [0..5]: node / point tests of the three traversal kernels
   OWLMI_HIP(hipMemsetAsync(counters_, 0, (kCounters + kDbStripes * 8) * sizeof(unsigned long long), s));  // ... [19]: length of the label pass's list
   const unsigned walk_grid = blocks < 2048u ? blocks : 2048u;  // grid-stride over lists whose lengths only the device knows
@@ -1254,6 +1279,13 @@ void Engine::dbscan(float eps, int min_pts, int32_t *d_labels, uint8_t *d_core, 
     info->union_launches = union_launches;
     info->union_node_tests = (int64_t)h_counters_[2];
     info->groups = per_point ? 0 : (int64_t)h_counters_[8];
+    if (a.diag & 512) {
+      unsigned long long t[8];
+      OWLMI_HIP(hipMemcpy(t, counters_ + 20, sizeof t, hipMemcpyDeviceToHost));
+      const double tot = (double)(t[0] + t[1] + t[2] + t[3] + t[4]);
+      std::fprintf(stderr, "[dbscan] union kernel wave time: loads %.1f%%  tests %.1f%%  settles %.1f%%  pushes %.1f%%  packet set-up %.1f%%;  %.1f rounds and %.1f settles per packet, %llu packet walks, %.1f us per packet walk (s_memtime at 100 MHz)\n",
+                   100 * t[0] / tot, 100 * t[1] / tot, 100 * t[2] / tot, 100 * t[3] / tot, 100 * t[4] / tot, (double)t[5] / (double)t[7], (double)t[6] / (double)t[7], t[7], tot / 100.0 / (double)t[7]);
+    }
     if (a.diag & 8)
       std::fprintf(stderr, "[dbscan] groups %llu  union-phase node tests %llu  longest walk %llu  mean of the waves' longest %.0f\n", h_counters_[8],
                    h_counters_[2], h_counters_[6], (double)h_counters_[7] / ((double)((h_counters_[8] + 63) / 64) + 1e-9));
