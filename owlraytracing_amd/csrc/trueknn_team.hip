@@ -90,7 +90,7 @@ struct TeamLayout {
   // prefetches one group of four past the end of a list rounded up to whole groups)
   static constexpr int kEntStride = kMaxPerQuery + 4;
   static constexpr int kLdsEnt = 4 * kEntStride * 4;
-  static constexpr int kLdsCand = NREG == 1 ? 4 * kCandCap * 8 : 0;
+  static constexpr int kLdsCand = 4 * kCandCap * 8;
   static constexpr int kOffMask = kLdsQrec + kLdsBlk;
   static constexpr int kOffShared = kOffMask + kLdsMask;
   static constexpr int kOffEnt = kOffShared + kLdsSharedPadded;
@@ -442,6 +442,13 @@ __device__ __forceinline__ void team_pass(const TeamArgs &a, const TeamLds &L, i
     // candidate mask: the slot of a candidate used to come from an LDS atomic -- a round trip through the LDS pipe in the
     // middle of every block step that had a candidate, in a kernel that is bound by the latency of such chains
     uint32_t fill_n = 0;
+    // four half-cleaners: a bitonic sequence of sixteen keys, one per lane of the team, into ascending order
+    auto clean16 = [&](uint32_t &kd, uint32_t &ki) {
+      exchange(kd, ki, t_dpp<0x128>(kd), t_dpp<0x128>(ki), up8);  // xor 8 (row_ror:8)
+      exchange(kd, ki, t_xor4(kd), t_xor4(ki), up4);
+      exchange(kd, ki, t_dpp<0x4e>(kd), t_dpp<0x4e>(ki), up2);
+      exchange(kd, ki, t_dpp<0xb1>(kd), t_dpp<0xb1>(ki), up1);
+    };
     auto merge_buffer = [&]() {
       t_wave_sync();
       const uint32_t fill = fill_n;
@@ -456,16 +463,31 @@ __device__ __forceinline__ void team_pass(const TeamArgs &a, const TeamLds &L, i
         const float dist = knn_sqrt(__uint_as_float((uint32_t)(key >> 32)));
         uint32_t kd = have ? __float_as_uint(dist) : 0x7f7fffffu, ki = have ? (uint32_t)key : 0u;  // KNN_EMPTY_KEY past the end
         sort16(kd, ki);
-        const uint32_t od = t_dpp<0x140>(kd), oi = t_dpp<0x140>(ki);  // sorted key 15 - tl
-        const uint64_t mine_k = ((uint64_t)bd[0] << 32) | bi[0], other = ((uint64_t)od << 32) | oi;
-        const bool take = other < mine_k;
-        if (full) left_out = min(left_out, take ? bd[0] : od);  // the key of the pair that finds no room (team minimum taken at the end)
-        bd[0] = take ? od : bd[0];
-        bi[0] = take ? oi : bi[0];
-        exchange(bd[0], bi[0], t_dpp<0x128>(bd[0]), t_dpp<0x128>(bi[0]), up8);  // xor 8 (row_ror:8)
-        exchange(bd[0], bi[0], t_xor4(bd[0]), t_xor4(bi[0]), up4);
-        exchange(bd[0], bi[0], t_dpp<0x4e>(bd[0]), t_dpp<0x4e>(bi[0]), up2);
-        exchange(bd[0], bi[0], t_dpp<0xb1>(bd[0]), t_dpp<0xb1>(bi[0]), up1);
+        // The sorted row meets the list one register (sixteen sorted entries, all of them below the next register's) at a
+        // time: mirrored, lane j against the row's key 15 - j, the sixteen smallest of both stay in the register and the
+        // sixteen largest travel on as the row for the next register -- both come out as bitonic sequences, four
+        // half-cleaners each.  A register no key of the row gets into is left as it is.  What comes out of the last register
+        // has fallen out of the list.
+#pragma unroll
+        for (int j = 0; j < NREG; j++) {
+          const uint32_t od = t_dpp<0x140>(kd), oi = t_dpp<0x140>(ki);  // the row's key 15 - tl
+          const uint64_t mine_k = ((uint64_t)bd[j] << 32) | bi[j], other = ((uint64_t)od << 32) | oi;
+          const bool take = other < mine_k;
+          if (NREG > 1 && __ballot(take) == 0ull) {  // every key of the row is larger than this whole register: on to the next
+            if (full && j == NREG - 1) left_out = min(left_out, kd);
+            continue;
+          }
+          const uint32_t hd = take ? bd[j] : od, hi_i = take ? bi[j] : oi;  // the larger of the pair: travels on (or falls out)
+          bd[j] = take ? od : bd[j];
+          bi[j] = take ? oi : bi[j];
+          clean16(bd[j], bi[j]);
+          if (j == NREG - 1) {
+            if (full) left_out = min(left_out, hd);  // the keys that find no room (team minimum taken at the end)
+          } else {
+            kd = hd, ki = hi_i;
+            clean16(kd, ki);
+          }
+        }
       }
       t_wave_sync();  // (the rows are read: the next candidates may overwrite them)
       fill_n = 0;
@@ -500,66 +522,21 @@ __device__ __forceinline__ void team_pass(const TeamArgs &a, const TeamLds &L, i
         unsigned long long pm = in_m & __ballot(d2 <= tau2);
         if (own_block) pm &= __ballot(p.id != t_qid);  // deviceCode.cu:103: a query is no neighbour of itself (ids are unique: only its own block holds it)
         if (TKNN_DIAG_BUILD && (a.diag & 1)) pm = 0;
-        if (NREG == 1) {
-          if (pm) {
-            if (TKNN_DIAG_BUILD && (a.diag & 16) && lane == 0) atomicAdd(&a.counters[26], (unsigned long long)__popcll(pm));
-            // my candidate into the team's buffer; a full row of sixteen is merged at once (a block
-            // adds at most sixteen to at most fifteen: the buffer holds 32)
-            const uint32_t mine16 = (uint32_t)(pm >> (team << 4)) & 0xffffu;  // my team's lanes with a candidate
-            if ((mine16 >> tl) & 1u) {
-              const unsigned long long key = ((unsigned long long)__float_as_uint(d2) << 32) | (uint32_t)p.id;  // (the root: merge_buffer)
-              L.cand[team * kCandCap + fill_n + __popc(mine16 & ((1u << tl) - 1u))] = key;
-            }
-            fill_n += __popc(mine16);
-            dirty = true;
-            if (__ballot(fill_n >= 16u) != 0ull) {
-              if (TKNN_DIAG_BUILD && (a.diag & 16) && lane == 0) atomicAdd(&a.counters[27], 1ull);
-              merge_buffer();
-            }
-          }
-        } else if (pm) {
-          // exact key of my candidate, then one team-parallel sorted insert per pending lane
-          const uint32_t key_d = __float_as_uint(knn_sqrt(d2));
-          const uint32_t key_i = (uint32_t)p.id;
+        if (pm) {
           if (TKNN_DIAG_BUILD && (a.diag & 16) && lane == 0) atomicAdd(&a.counters[26], (unsigned long long)__popcll(pm));
-          do {
+          // my candidate into the team's buffer; a full row of sixteen is merged at once (a block
+          // adds at most sixteen to at most fifteen: the buffer holds 32)
+          const uint32_t mine16 = (uint32_t)(pm >> (team << 4)) & 0xffffu;  // my team's lanes with a candidate
+          if ((mine16 >> tl) & 1u) {
+            const unsigned long long key = ((unsigned long long)__float_as_uint(d2) << 32) | (uint32_t)p.id;  // (the root: merge_buffer)
+            L.cand[team * kCandCap + fill_n + __popc(mine16 & ((1u << tl) - 1u))] = key;
+          }
+          fill_n += __popc(mine16);
+          dirty = true;
+          if (__ballot(fill_n >= 16u) != 0ull) {
             if (TKNN_DIAG_BUILD && (a.diag & 16) && lane == 0) atomicAdd(&a.counters[27], 1ull);
-            const uint32_t pending_mine = (uint32_t)(pm >> (team * 16)) & 0xffffu;  // pending lanes of my team
-            const bool has = pending_mine != 0u;
-            const int src = (team << 4) + (has ? __ffs((int)pending_mine) - 1 : 0);
-            const uint32_t cd = t_lane_read(key_d, src), ci = t_lane_read(key_i, src);
-            const uint64_t c = ((uint64_t)cd << 32) | ci;
-            // every register shifts like one 16 * NREG long list: lane 0 of register j follows lane 15 of
-            // register j - 1 (row_ror:1 brings it round; combined with a lane mask, not with a select:
-            // hipcc 7.2 miscompiles a select between two DPP moves -- lane 0 of the row reads 0; checked
-            // with a 20-line kernel on gfx950).  A team with nothing to insert in this step keeps its
-            // list (has is uniform per team).
-            const uint32_t lane0 = tl == 0 ? 0xffffffffu : 0u;
-            uint32_t nd_[NREG], ni_[NREG];
-#pragma unroll
-            for (int j = 0; j < NREG; j++) {
-              const uint64_t cur = ((uint64_t)bd[j] << 32) | bi[j];
-              uint32_t pd = t_team_shr1(bd[j]), pi = t_team_shr1(bi[j]);
-              if (j > 0) {
-                pd |= t_dpp<0x121>(bd[j - 1]) & lane0;
-                pi |= t_dpp<0x121>(bi[j - 1]) & lane0;
-              }
-              const uint64_t prev = ((uint64_t)pd << 32) | pi;  // entry 0: key 0, never greater than c
-              const bool take_prev = has & ((j > 0) | (tl != 0)) & (c < prev);
-              const bool take_c = has & (c < cur);
-              const uint64_t nw = take_prev ? prev : (take_c ? c : cur);
-              if (full && j == NREG - 1) left_out = has ? min(left_out, take_c ? bd[j] : cd) : left_out;
-              nd_[j] = (uint32_t)(nw >> 32);
-              ni_[j] = (uint32_t)nw;
-            }
-#pragma unroll
-            for (int j = 0; j < NREG; j++) {
-              bd[j] = nd_[j];
-              bi[j] = ni_[j];
-            }
-            pm &= ~__ballot(lane == src);  // the four lanes just served (a team without one names a lane that was not pending)
-          } while (pm);
-          tau2 = knn_gate_from_worst(kth_dist());
+            merge_buffer();
+          }
         }
       }
     };
@@ -634,17 +611,17 @@ __device__ __forceinline__ void team_pass(const TeamArgs &a, const TeamLds &L, i
       b3 = fetch(g.w);
       // a tighter gate for the next group as soon as a handful of candidates wait (the first groups, whose
       // blocks lie next to the query, bring most of them)
-      if (SELECT && NREG == 1 && dirty && __ballot(fill_n >= (uint32_t)TKNN_MERGE_AT) != 0ull) {
+      if (SELECT && dirty && __ballot(fill_n >= (uint32_t)TKNN_MERGE_AT) != 0ull) {
         if (TKNN_DIAG_BUILD && (a.diag & 16) && lane == 0) atomicAdd(&a.counters[27], 1ull);
         merge_buffer();
       }
       TP_LAP(it == 0 ? 1 : 2);
     }
-    if (SELECT && NREG == 1 && dirty) {
+    if (SELECT && dirty) {
       if (TKNN_DIAG_BUILD && (a.diag & 16) && lane == 0) atomicAdd(&a.counters[27], 1ull);
       merge_buffer();
     }
-    if (SELECT && NREG == 1 && full) {
+    if (SELECT && full) {
       // the smallest key left out by any merge, where the tie test below looks for it: lane 15
       uint32_t v = left_out;
       v = min(v, (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)v, 0x128 /*row_ror:8*/, 0xf, 0xf, false));
