@@ -79,7 +79,8 @@ constexpr int kLdsShared = (kLdsCnt + kLdsList) > kLdsStack ? (kLdsCnt + kLdsLis
 constexpr int kLdsSharedPadded = (kLdsShared + 15) & ~15;  // the entry lists are read 16 bytes at a time
 // per team (k <= 16): candidates that passed the gate since the last merge into the team's sorted list, as
 // 64-bit (dist, index) keys, and how many there are.  At most 16 when a block is tested, so 32 hold any block.
-constexpr int kCandCap = 32;
+constexpr int kCandCapacity = 32;
+constexpr int kCandCap = kCandCapacity;
 // LDS per wave, by the number of list registers per lane: query records | block list | per-query block lists |
 // counts, query list / pyramid stack | per-team entry lists | per-team candidate buffers (k <= 16 only)
 template <int NREG>
@@ -261,6 +262,82 @@ __device__ __forceinline__ int32_t resolve_entry(int32_t e) {
   return HALO ? e : (int32_t)((uint32_t)e * (uint32_t)(LBVH_BLOCK * sizeof(LbvhPoint)));
 }
 
+// ---- a team's sorted list and its candidate buffer ---------------------------------------------------------------------
+// One compare-exchange with the lane whose key is (pd, pi): the lower lane keeps the smaller key.
+__device__ __forceinline__ void t_exchange(uint32_t &kd, uint32_t &ki, uint32_t pd, uint32_t pi, bool upper) {
+  const uint64_t mine_k = ((uint64_t)kd << 32) | ki, other = ((uint64_t)pd << 32) | pi;
+  const bool take = (other < mine_k) != upper;  // lower lane: the smaller key; upper lane: the larger (equal: either)
+  kd = take ? pd : kd;
+  ki = take ? pi : ki;
+}
+// 16 keys of a team, one per lane, into ascending order: a bitonic network written so that every exchange
+// keeps the smaller key in the lower lane -- mirror within 2, 4, 8, 16 lanes followed by xor 4 / 2 / 1
+// steps; ten exchanges of DPP moves (quad permutes, mirrors, row shifts) and a 64-bit compare each.
+__device__ __forceinline__ void t_sort16(uint32_t &kd, uint32_t &ki, int tl) {
+  const bool up1 = (tl & 1) != 0, up2 = (tl & 2) != 0, up4 = (tl & 4) != 0, up8 = (tl & 8) != 0;
+  t_exchange(kd, ki, t_dpp<0xb1>(kd), t_dpp<0xb1>(ki), up1);    // pairs
+  t_exchange(kd, ki, t_dpp<0x1b>(kd), t_dpp<0x1b>(ki), up2);    // mirror within 4
+  t_exchange(kd, ki, t_dpp<0xb1>(kd), t_dpp<0xb1>(ki), up1);
+  t_exchange(kd, ki, t_dpp<0x141>(kd), t_dpp<0x141>(ki), up4);  // mirror within 8 (row_half_mirror)
+  t_exchange(kd, ki, t_dpp<0x4e>(kd), t_dpp<0x4e>(ki), up2);    // xor 2
+  t_exchange(kd, ki, t_dpp<0xb1>(kd), t_dpp<0xb1>(ki), up1);
+  t_exchange(kd, ki, t_dpp<0x140>(kd), t_dpp<0x140>(ki), up8);  // mirror within 16 (row_mirror)
+  t_exchange(kd, ki, t_xor4(kd), t_xor4(ki), up4);
+  t_exchange(kd, ki, t_dpp<0x4e>(kd), t_dpp<0x4e>(ki), up2);
+  t_exchange(kd, ki, t_dpp<0xb1>(kd), t_dpp<0xb1>(ki), up1);
+}
+// four half-cleaners: a bitonic sequence of sixteen keys, one per lane of the team, into ascending order
+__device__ __forceinline__ void t_clean16(uint32_t &kd, uint32_t &ki, int tl) {
+  const bool up1 = (tl & 1) != 0, up2 = (tl & 2) != 0, up4 = (tl & 4) != 0, up8 = (tl & 8) != 0;
+  t_exchange(kd, ki, t_dpp<0x128>(kd), t_dpp<0x128>(ki), up8);  // xor 8 (row_ror:8)
+  t_exchange(kd, ki, t_xor4(kd), t_xor4(ki), up4);
+  t_exchange(kd, ki, t_dpp<0x4e>(kd), t_dpp<0x4e>(ki), up2);
+  t_exchange(kd, ki, t_dpp<0xb1>(kd), t_dpp<0xb1>(ki), up1);
+}
+// Candidates that pass a team's gate are not inserted one lock-step round each: they wait in the team's LDS buffer as
+// (squared distance, index) and are MERGED into the sorted list sixteen at a time.  `buf`: my team's buffer, `fill`: how
+// many wait (the same in the team's lanes).  Per row of sixteen: the IEEE root (sixteen instructions, once per row and not
+// per block step), the sorting network, then the row meets the list one register (sixteen sorted entries, all of them
+// below the next register's) at a time: mirrored, lane j against the row's key 15 - j, the sixteen smallest of both stay
+// in the register and the sixteen largest travel on as the row for the next register -- both come out as bitonic
+// sequences, four half-cleaners each.  A register no key of the row gets into is left as it is.  What comes out of the
+// last register has fallen out of the list (`left_out`, tracked if `full`: its smallest distance, team minimum taken by
+// the caller).  Some 80 vector instructions per row for k <= 16, 250 for k <= 64, whatever the number of candidates.
+template <int NREG>
+__device__ __forceinline__ void t_merge_rows(uint32_t (&bd)[NREG], uint32_t (&bi)[NREG], uint32_t &left_out, bool full,
+                                             const unsigned long long *buf, uint32_t fill, int tl) {
+#pragma unroll
+  for (int row = 0; row < kCandCapacity / 16; row++) {
+    if (row > 0 && __ballot(fill > 16u * (uint32_t)row) == 0ull) break;
+    const uint32_t at = 16u * (uint32_t)row + (uint32_t)tl;
+    const bool have = at < fill;
+    const unsigned long long key = have ? buf[at] : 0ull;
+    const float dist = knn_sqrt(__uint_as_float((uint32_t)(key >> 32)));
+    uint32_t kd = have ? __float_as_uint(dist) : 0x7f7fffffu, ki = have ? (uint32_t)key : 0u;  // KNN_EMPTY_KEY past the end
+    t_sort16(kd, ki, tl);
+#pragma unroll
+    for (int j = 0; j < NREG; j++) {
+      const uint32_t od = t_dpp<0x140>(kd), oi = t_dpp<0x140>(ki);  // the row's key 15 - tl
+      const uint64_t mine_k = ((uint64_t)bd[j] << 32) | bi[j], other = ((uint64_t)od << 32) | oi;
+      const bool take = other < mine_k;
+      if (NREG > 1 && __ballot(take) == 0ull) {  // every key of the row is larger than this whole register: on to the next
+        if (full && j == NREG - 1) left_out = min(left_out, kd);
+        continue;
+      }
+      const uint32_t hd = take ? bd[j] : od, hi_i = take ? bi[j] : oi;  // the larger of the pair: travels on (or falls out)
+      bd[j] = take ? od : bd[j];
+      bi[j] = take ? oi : bi[j];
+      t_clean16(bd[j], bi[j], tl);
+      if (j == NREG - 1) {
+        if (full) left_out = min(left_out, hd);
+      } else {
+        kd = hd, ki = hi_i;
+        t_clean16(kd, ki, tl);
+      }
+    }
+  }
+}
+
 struct TeamLds {
   float *qrec;        // [64][kQrecStride]
   int32_t *blk;       // [kMaxBlocks] block entries of the packet (bit 31: halo tree)
@@ -405,90 +482,17 @@ __device__ __forceinline__ void team_pass(const TeamArgs &a, const TeamLds &L, i
       return __uint_as_float(t_lane_read(reg, (team << 4) + ((a.k - 1) & 15)));
     };
     float tau2 = INFINITY;
-    // ---- sorting network pieces (k <= 16: the list is one register pair, lane j holds entry j) ----------
-    const bool up1 = (tl & 1) != 0, up2 = (tl & 2) != 0, up4 = (tl & 4) != 0, up8 = (tl & 8) != 0;
-    // one compare-exchange with the lane whose key is (pd, pi): the lower lane keeps the smaller key
-    auto exchange = [&](uint32_t &kd, uint32_t &ki, uint32_t pd, uint32_t pi, bool upper) {
-      const uint64_t mine_k = ((uint64_t)kd << 32) | ki, other = ((uint64_t)pd << 32) | pi;
-      const bool take = (other < mine_k) != upper;  // lower lane: the smaller key; upper lane: the larger (equal: either)
-      kd = take ? pd : kd;
-      ki = take ? pi : ki;
-    };
-    // 16 keys of a team, one per lane, into ascending order: a bitonic network written so that every exchange
-    // keeps the smaller key in the lower lane -- mirror within 2, 4, 8, 16 lanes followed by xor 4 / 2 / 1
-    // steps; ten exchanges of DPP moves (quad permutes, mirrors, row shifts) and a 64-bit compare each.
-    auto sort16 = [&](uint32_t &kd, uint32_t &ki) {
-      exchange(kd, ki, t_dpp<0xb1>(kd), t_dpp<0xb1>(ki), up1);    // pairs
-      exchange(kd, ki, t_dpp<0x1b>(kd), t_dpp<0x1b>(ki), up2);    // mirror within 4
-      exchange(kd, ki, t_dpp<0xb1>(kd), t_dpp<0xb1>(ki), up1);
-      exchange(kd, ki, t_dpp<0x141>(kd), t_dpp<0x141>(ki), up4);  // mirror within 8 (row_half_mirror)
-      exchange(kd, ki, t_dpp<0x4e>(kd), t_dpp<0x4e>(ki), up2);    // xor 2
-      exchange(kd, ki, t_dpp<0xb1>(kd), t_dpp<0xb1>(ki), up1);
-      exchange(kd, ki, t_dpp<0x140>(kd), t_dpp<0x140>(ki), up8);  // mirror within 16 (row_mirror)
-      exchange(kd, ki, t_xor4(kd), t_xor4(ki), up4);
-      exchange(kd, ki, t_dpp<0x4e>(kd), t_dpp<0x4e>(ki), up2);
-      exchange(kd, ki, t_dpp<0xb1>(kd), t_dpp<0xb1>(ki), up1);
-    };
-    // k <= 16: candidates that pass the gate are not inserted one lock-step round each (7.4 rounds of some
-    // 25 vector instructions per query on the benchmark, two LDS-crossbar reads each: a third of the
-    // kernel's vector work for 11.6 candidates per query).  They go to the team's LDS buffer -- a slot from
-    // an LDS counter, no cross-lane traffic -- and are MERGED into the sorted list sixteen at a time: sort
-    // the sixteen (network above), meet the list mirrored (lane j against sorted key 15 - j: the sixteen
-    // smallest of both survive, as a bitonic sequence), four half-cleaners.  Some 80 vector instructions
-    // whatever the number of candidates, no LDS crossbar, no scalar mask arithmetic.  Between merges the
-    // gate is the last merge's k-th distance: looser than it could be, never wrong.
+    // Candidates that pass the gate wait in the team's LDS buffer and are merged into the sorted list sixteen at a time
+    // (t_merge_rows).  Between merges the gate is the last merge's k-th distance: looser than it could be, never wrong.
     bool dirty = false;  // wave-uniform: some team has buffered candidates
     // how many wait in my team's buffer (the same in its sixteen lanes).  In a register, advanced by population counts of the
     // candidate mask: the slot of a candidate used to come from an LDS atomic -- a round trip through the LDS pipe in the
     // middle of every block step that had a candidate, in a kernel that is bound by the latency of such chains
     uint32_t fill_n = 0;
-    // four half-cleaners: a bitonic sequence of sixteen keys, one per lane of the team, into ascending order
-    auto clean16 = [&](uint32_t &kd, uint32_t &ki) {
-      exchange(kd, ki, t_dpp<0x128>(kd), t_dpp<0x128>(ki), up8);  // xor 8 (row_ror:8)
-      exchange(kd, ki, t_xor4(kd), t_xor4(ki), up4);
-      exchange(kd, ki, t_dpp<0x4e>(kd), t_dpp<0x4e>(ki), up2);
-      exchange(kd, ki, t_dpp<0xb1>(kd), t_dpp<0xb1>(ki), up1);
-    };
+    auto sort16 = [&](uint32_t &kd, uint32_t &ki) { t_sort16(kd, ki, tl); };
     auto merge_buffer = [&]() {
       t_wave_sync();
-      const uint32_t fill = fill_n;
-#pragma unroll
-      for (int row = 0; row < kCandCap / 16; row++) {
-        if (row > 0 && __ballot(fill > 16u * (uint32_t)row) == 0ull) break;
-        const uint32_t at = 16u * (uint32_t)row + (uint32_t)tl;
-        // the buffer holds (squared distance, index): the IEEE square root -- sixteen instructions -- is taken here, once
-        // per merged row, not at every block that has a candidate for some team (four of five blocks on the benchmark)
-        const bool have = at < fill;
-        const unsigned long long key = have ? L.cand[team * kCandCap + at] : 0ull;
-        const float dist = knn_sqrt(__uint_as_float((uint32_t)(key >> 32)));
-        uint32_t kd = have ? __float_as_uint(dist) : 0x7f7fffffu, ki = have ? (uint32_t)key : 0u;  // KNN_EMPTY_KEY past the end
-        sort16(kd, ki);
-        // The sorted row meets the list one register (sixteen sorted entries, all of them below the next register's) at a
-        // time: mirrored, lane j against the row's key 15 - j, the sixteen smallest of both stay in the register and the
-        // sixteen largest travel on as the row for the next register -- both come out as bitonic sequences, four
-        // half-cleaners each.  A register no key of the row gets into is left as it is.  What comes out of the last register
-        // has fallen out of the list.
-#pragma unroll
-        for (int j = 0; j < NREG; j++) {
-          const uint32_t od = t_dpp<0x140>(kd), oi = t_dpp<0x140>(ki);  // the row's key 15 - tl
-          const uint64_t mine_k = ((uint64_t)bd[j] << 32) | bi[j], other = ((uint64_t)od << 32) | oi;
-          const bool take = other < mine_k;
-          if (NREG > 1 && __ballot(take) == 0ull) {  // every key of the row is larger than this whole register: on to the next
-            if (full && j == NREG - 1) left_out = min(left_out, kd);
-            continue;
-          }
-          const uint32_t hd = take ? bd[j] : od, hi_i = take ? bi[j] : oi;  // the larger of the pair: travels on (or falls out)
-          bd[j] = take ? od : bd[j];
-          bi[j] = take ? oi : bi[j];
-          clean16(bd[j], bi[j]);
-          if (j == NREG - 1) {
-            if (full) left_out = min(left_out, hd);  // the keys that find no room (team minimum taken at the end)
-          } else {
-            kd = hd, ki = hi_i;
-            clean16(kd, ki);
-          }
-        }
-      }
+      t_merge_rows<NREG>(bd, bi, left_out, full, L.cand + team * kCandCap, fill_n, tl);
       t_wave_sync();  // (the rows are read: the next candidates may overwrite them)
       fill_n = 0;
       dirty = false;
@@ -1259,6 +1263,7 @@ template <bool HALO, int NREG>
 __global__ void __launch_bounds__(kTeamBlock) team_walk_kernel(TeamArgs a, const int32_t *slots, int32_t nslots) {
   __shared__ int32_t stack_mem[4 * kWalkStack];
   __shared__ WalkLevel levels[2][LBVH_WIDE_LEVELS];
+  __shared__ unsigned long long cand_mem[4 * kCandCapacity];  // per team: candidates waiting to be merged into its list (t_merge_rows)
   const int lane = threadIdx.x & 63, team = lane >> 4, tl = lane & 15;
   int32_t *stack = stack_mem + team * kWalkStack;
   if (lane < 2 * LBVH_WIDE_LEVELS) {
@@ -1307,6 +1312,17 @@ __global__ void __launch_bounds__(kTeamBlock) team_walk_kernel(TeamArgs a, const
 #pragma unroll
         for (int j = 1; j < NREG; j++) reg = ((a.k - 1) >> 4) == j ? bd[j] : reg;
         return __uint_as_float(t_lane_read(reg, (team << 4) + ((a.k - 1) & 15)));
+      };
+      // candidates wait in the team's buffer and are merged sixteen at a time, as in the passes (one insert per lock-step
+      // round was most of this kernel's time at k = 64: some 200 inserts per query)
+      unsigned long long *my_cand = cand_mem + team * kCandCapacity;
+      uint32_t fill_n = 0;
+      auto merge_buffer = [&]() {
+        t_wave_sync();
+        t_merge_rows<NREG>(bd, bi, left_out, full, my_cand, fill_n, tl);
+        t_wave_sync();
+        fill_n = 0;
+        tau2 = knn_gate_from_worst(kth_dist());
       };
       for (int tree = 0; tree < (HALO ? 2 : 1); tree++) {
         const LbvhWideView &wv = a.wide[tree];
@@ -1389,48 +1405,28 @@ __global__ void __launch_bounds__(kTeamBlock) team_walk_kernel(TeamArgs a, const
                 unsigned long long pm = in_m & __ballot(p.id != q.id) & __ballot(d2 <= tau2);
                 if (TKNN_DIAG_BUILD && (a.diag & 1)) pm = 0;
                 if (pm) {
-                  const uint32_t key_d = __float_as_uint(knn_sqrt(d2));
-                  const uint32_t key_i = (uint32_t)p.id;
-                  do {
-                    const uint32_t pending_mine = (uint32_t)(pm >> (team * 16)) & 0xffffu;
-                    const bool has = pending_mine != 0u;
-                    const int src = (team << 4) + (has ? __ffs((int)pending_mine) - 1 : 0);
-                    const uint32_t cd = t_lane_read(key_d, src), ci = t_lane_read(key_i, src);
-                    const uint64_t cc = ((uint64_t)cd << 32) | ci;
-                    // every register shifts like one 16 * NREG long list: lane 0 of register j follows lane 15
-                    // of register j - 1 (row_ror:1 brings it round; combined by mask, see team_pass)
-                    const uint32_t lane0 = tl == 0 ? 0xffffffffu : 0u;
-                    uint32_t nd_[NREG], ni_[NREG];
-#pragma unroll
-                    for (int j = 0; j < NREG; j++) {
-                      const uint64_t cur = ((uint64_t)bd[j] << 32) | bi[j];
-                      uint32_t pd = t_team_shr1(bd[j]), pi = t_team_shr1(bi[j]);
-                      if (j > 0) {
-                        pd |= t_dpp<0x121>(bd[j - 1]) & lane0;
-                        pi |= t_dpp<0x121>(bi[j - 1]) & lane0;
-                      }
-                      const uint64_t prev = ((uint64_t)pd << 32) | pi;  // list entry before mine (entry 0: key 0, never above cc)
-                      const bool take_prev = has & ((j > 0) | (tl != 0)) & (cc < prev);
-                      const bool take_c = has & (cc < cur);
-                      const uint64_t nw = take_prev ? prev : (take_c ? cc : cur);
-                      if (j == NREG - 1 && full) left_out = has ? min(left_out, take_c ? bd[j] : cd) : left_out;
-                      nd_[j] = (uint32_t)(nw >> 32);
-                      ni_[j] = (uint32_t)nw;
-                    }
-#pragma unroll
-                    for (int j = 0; j < NREG; j++) {
-                      bd[j] = nd_[j];
-                      bi[j] = ni_[j];
-                    }
-                    pm &= ~__ballot(lane == src);
-                  } while (pm);
-                  tau2 = knn_gate_from_worst(kth_dist());
+                  const uint32_t mine16 = (uint32_t)(pm >> (team << 4)) & 0xffffu;  // my team's lanes with a candidate
+                  if ((mine16 >> tl) & 1u) my_cand[fill_n + __popc(mine16 & ((1u << tl) - 1u))] = ((unsigned long long)__float_as_uint(d2) << 32) | (uint32_t)p.id;
+                  fill_n += __popc(mine16);
+                  if (__ballot(fill_n >= 16u) != 0ull) merge_buffer();
                 }
               }
+              // a tighter gate for what comes next as soon as a handful of candidates wait
+              if (__ballot(fill_n >= (uint32_t)TKNN_MERGE_AT) != 0ull) merge_buffer();
             }
           }
           t_wave_sync();
         }
+      }
+      if (__ballot(fill_n > 0u) != 0ull) merge_buffer();
+      if (full) {
+        // the smallest key left out by any merge, where the tie test below looks for it: lane 15
+        uint32_t v = left_out;
+        v = min(v, (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)v, 0x128 /*row_ror:8*/, 0xf, 0xf, false));
+        v = min(v, (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)v, 0x124 /*row_ror:4*/, 0xf, 0xf, false));
+        v = min(v, (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)v, 0x122 /*row_ror:2*/, 0xf, 0xf, false));
+        v = min(v, (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)v, 0x121 /*row_ror:1*/, 0xf, 0xf, false));
+        left_out = v;
       }
       // ---- the level's outcome, per team ----
       const uint32_t cnt = t_team_sum(part);
