@@ -53,7 +53,10 @@ constexpr int kMaxBlocks = 256;     // leaf blocks one packet may need per level
 #endif
 // leaf blocks one query may need per level: k <= 16 (one list register per lane) 72 -- lists of the benchmark run to 60 --,
 // larger k 96 (a third of the queries of 10 M uniform points need more than 72 at k = 32 and would be handed over)
-constexpr int max_per_query(int nreg) { return nreg == 1 ? TKNN_MAX_PER_QUERY : 96; }
+#ifndef TKNN_MAX_PER_QUERY_4
+#define TKNN_MAX_PER_QUERY_4 96  // (k > 32)
+#endif
+constexpr int max_per_query(int nreg) { return nreg == 1 ? TKNN_MAX_PER_QUERY : (nreg == 4 ? TKNN_MAX_PER_QUERY_4 : 96); }
 #ifndef TKNN_MERGE_AT
 #define TKNN_MERGE_AT 12  // buffered candidates of some team at the end of a group of four blocks that trigger a merge
 #endif
@@ -98,7 +101,7 @@ struct TeamLayout {
   static constexpr int kOffCand = kOffEnt + kLdsEnt;
   static constexpr int kTeamLds = kOffCand + kLdsCand;
   static_assert(kEntStride % 4 == 0 && kOffEnt % 16 == 0, "entry lists must be 16-byte aligned");
-  static_assert(kMaxPerQuery <= 96 && kMaxPerQuery / 4 < 32, "list-length buckets of the pass lists are one bit each of a 32-bit word");
+  static_assert(kMaxPerQuery <= 124 && kMaxPerQuery / 4 < 32, "list-length buckets of the pass lists are one bit each of a 32-bit word");
 };
 
 // LDS query record: [0..2] q, [3] id, [4] radius of the box the pass works in (outermost level of
