@@ -723,9 +723,10 @@ __global__ void __launch_bounds__(kTeamBlock) __attribute__((amdgpu_waves_per_eu
   unsigned long long *cand = (unsigned long long *)(base + Lay::kOffCand);  // (k <= 16 only: zero bytes otherwise, never touched)
 
   const LbvhPoint *own_pts = a.bvh.points + tl, *halo_pts = a.halo.points ? a.halo.points + tl : a.bvh.points + tl;
-  unsigned long long my_isect_sum = 0, my_levels = 0, my_unfinished = 0, wave_node_tests = 0, wave_point_tests = 0;
+  unsigned long long my_isect_sum = 0, wave_node_tests = 0, wave_point_tests = 0;
+  uint32_t my_levels = 0, my_unfinished = 0;  // (per lane, a few dozen packets each: 32 bits, a register less apiece -- the kernel sits at its 128)
   int wave_levels = 0, wave_err = 0;
-  unsigned long long my_handed = 0;
+  uint32_t my_handed = 0;
   [[maybe_unused]] unsigned long long diag_scanned = 0, diag_listed = 0;  // TKNN_DIAG_BUILD only
   int wave_min_handover = 0x7fffffff;
 #if TKNN_DIAG_BUILD
@@ -1171,7 +1172,7 @@ __global__ void __launch_bounds__(kTeamBlock) __attribute__((amdgpu_waves_per_eu
         levels_run = finished ? fin_at + 1 : m;
         isect += c0;
         if (levels_run > 1) isect += c1;
-        my_levels += (unsigned long long)levels_run;
+        my_levels += (uint32_t)levels_run;
         last_others = (m > 1 ? c1 : c0) - selfc;
         prev_others = last_others;
       }
@@ -1217,7 +1218,8 @@ __global__ void __launch_bounds__(kTeamBlock) __attribute__((amdgpu_waves_per_eu
     if (active) my_unfinished++;
   }
 
-  const unsigned long long isum = t_wave_sum(my_isect_sum), lsum = t_wave_sum(my_levels), usum = t_wave_sum(my_unfinished), hsum = t_wave_sum(my_handed);
+  const unsigned long long isum = t_wave_sum(my_isect_sum), lsum = t_wave_sum((unsigned long long)my_levels), usum = t_wave_sum((unsigned long long)my_unfinished),
+                           hsum = t_wave_sum((unsigned long long)my_handed);
   if (lane == 0) {
     atomicMax(&a.counters[1], (unsigned long long)wave_levels);
     atomicAdd(&a.counters[2], wave_node_tests);
