@@ -467,7 +467,7 @@ void Buffer::allocate(const void *init) {
   if (bkind == BufferKind::Device) {
     OWL_HIP(hipMalloc(&ptr, n ? n : 16));
     if (init && n) OWL_HIP(hipMemcpy(ptr, init, n, hipMemcpyHostToDevice));
-  } else if (bkind == BufferKind::Managed && managed_policy() == 4) {
+  } else if (bkind == BufferKind::Managed && (managed_policy() == 4 || managed_policy() == 5)) {
     // mirror form: device memory + pinned host copy (one address per side; see struct Buffer)
     mirrored = true;
     OWL_HIP(hipMalloc(&ptr, n ? n : 16));
@@ -730,6 +730,9 @@ void build_sbt(Context &c, int flags) {
 //   4 (default) mirror form: device memory for device code, a pinned host copy for owlBufferGetPointer, one bulk copy
 //     each way at the API's synchronisation points (struct Buffer).  The sample at 1 M points, k = 10: three rounds in
 //     about a quarter of the time of policy 0 (profiles/).
+//   5 (opt-in) as 4, for applications whose HOST code only reads its managed buffers (the TrueKNN sample's loop does): no
+//     mirror -> device copy before a launch -- what the host writes through the pointer never reaches the device
+//     (owlBufferUpload still does).  The sample's three rounds at 1 M points: 57 -> 46 ms.
 //   0: hipMallocManaged, prefetched to the GPU before a launch, pulled back by the host's page faults (round 1: the
 //      migration path moves 240 MB in about 70 ms each way on this system).  1: also prefetched to the host after a
 //      synchronous launch (slower still).  2 / 3: as 1 / 0 without the preferred-location advice.
@@ -758,6 +761,7 @@ const void *Buffer::host_pointer() {
 // legal look at the buffer since, and the copy would overwrite that launch's results.
 void Buffer::write_back(hipStream_t s) {
   if (!mirrored || !handed_out || device_newer || !ptr) return;
+  if (managed_policy() == 5) return;  // the application has declared that its host code only READS managed buffers
   OWL_HIP(hipMemcpyAsync(ptr, mirror, bytes() ? bytes() : 16, hipMemcpyHostToDevice, s));
 }
 
@@ -1140,6 +1144,7 @@ OWL_API void owlBufferUpload(OWLBuffer buffer, const void *host, size_t offset, 
     OWL_HIP(hipMemcpy((char *)b->ptr + offset, host, numBytes, hipMemcpyHostToDevice));
   } else if (b->mirrored) {
     std::memcpy((char *)b->host_pointer() + offset, host, numBytes);  // (refreshes the mirror first; written back before the next launch)
+    if (managed_policy() == 5) OWL_HIP(hipMemcpy((char *)b->ptr + offset, host, numBytes, hipMemcpyHostToDevice));  // (no write-back under this policy)
   } else {
     std::memcpy((char *)b->ptr + offset, host, numBytes);
   }

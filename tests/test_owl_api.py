@@ -195,6 +195,29 @@ def test_managed_buffer_pointer_held_across_launches(tmp_path, policy):
 
 
 @pytest.mark.gpu
+def test_read_only_mirror_policy_gives_the_same_rows(tmp_path):
+    """OWL_MANAGED_POLICY=5 (opt-in, for applications whose host code only reads its managed buffers): no mirror -> device
+    copy before a launch.  The TrueKNN loop (it only reads its frameBuffer) gets the rows of the default policy."""
+    if not os.path.exists(REF_HSACO):
+        pytest.skip("oracle/_ref/deviceCode.hsaco not built (no reference tree at build time)")
+    _need_driver()
+    import oracle
+    from owlraytracing_amd import datasets
+    n, k = 15000, 6
+    pts = datasets.uniform3d(n, seed=18)
+    r0 = float(np.float32(datasets.start_radius(n, k)))
+    (tmp_path / "pts.f32").write_bytes(pts.tobytes())
+    out = tmp_path / "fb.bin"
+    r = subprocess.run([DRIVER, "knn", REF_HSACO, str(tmp_path / "pts.f32"), str(n), str(k), repr(r0), str(out)],
+                       capture_output=True, text=True, timeout=600, env=dict(os.environ, OWL_MANAGED_POLICY="5"))
+    assert r.returncode == 0, r.stdout + r.stderr
+    ref = oracle.trueknn(pts, k, r0)
+    assert "rounds=%d " % ref["rounds"] in r.stdout, r.stdout
+    fb = np.frombuffer(out.read_bytes(), dtype=oracle.NEIGH_DTYPE).reshape(n, k)
+    assert np.array_equal(fb["dist"], ref["dist"]) and np.array_equal(fb["intersections"][:, 0], ref["intersections"])
+
+
+@pytest.mark.gpu
 def test_rtdbscan_sample_on_the_program_model(tmp_path):
     """samples/s02-rtdbscan -- RT-DBSCAN written as an OWL application (host code on owl* only; ONE intersection program
     that counts neighbours, unites core points with atomics in a union-find and assigns border points; two launches
