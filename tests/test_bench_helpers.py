@@ -49,3 +49,41 @@ def test_a_record_of_other_sources_is_not_attached(monkeypatch):
     assert rec is None and "other kernel sources" in why
     rec, why = bench.committed_profile("team_kernel", n + 1, k)
     assert rec is None and "no PMC record" in why
+
+
+def test_dbscan_rooflines_cover_the_three_traversal_kernels(monkeypatch):
+    """bench.py reports a roofline per traversal kernel of a tknnDbscan call (not only the one with the largest
+    sum): algorithmic bytes by the contract's formula, the kernel's own HIP-event time, PMC traffic only from a record of
+    these sources."""
+    bench = _bench()
+    info = {"core_ms": 0.66, "union_ms": 2.0, "label_ms": 0.5, "union_launches": 2, "union_node_tests": 15_000_000, "groups": 527_401,
+            "core_point_tests": 2_600_000, "union_point_tests": 1_000_000, "label_point_tests": 40_000}
+    monkeypatch.setattr(bench, "committed_profile", lambda kernel, n, k: ({"bytes_per_launch": 472_000_000, "wave_wait_frac": 0.8}, None)
+                        if kernel == "db_core_kernel" else (None, "no PMC record for this kernel and size"))
+    r = bench.dbscan_rooflines(info, [info, info], 10_000_000, 4)
+    assert set(r) == {"db_core_kernel", "db_group_union_kernel", "db_label_kernel"}
+    core = r["db_core_kernel"]
+    assert core["algorithmic_bytes_per_launch"] == 12 * 2_600_000 + 12 * 10_000_000 + 1 * 10_000_000
+    assert core["traffic"] == 472_000_000 and abs(core["traffic_over_algorithmic"] - 472e6 / core["algorithmic_bytes_per_launch"]) < 1e-9
+    assert abs(core["achieved"] - core["algorithmic_bytes_per_launch"] / 0.66e-3 / 1e9) < 1e-6 and core["frac"] == core["achieved"] / 8000.0
+    union = r["db_group_union_kernel"]
+    assert union["launches_per_step"] == 2 and abs(union["kernel_ms"] - 1.0) < 1e-12
+    assert union["algorithmic_bytes_per_launch"] == (32 * 15_000_000 + 12 * 1_000_000 + 32 * 527_401 * 2) // 2
+    assert union["traffic"] is None and "no PMC record" in union["traffic_note"]
+    assert r["db_label_kernel"]["algorithmic_bytes_per_launch"] == 12 * 40_000 + 12 * 10_000_000 + 4 * 10_000_000
+
+
+def test_sharded_infos_of_two_calls_merge_into_one_solve():
+    """ShardedTrueKNN._merge_infos: a solve and the re-solve of its stragglers (tknnSolveOptions.phase = 3) are one solve --
+    work adds up, the stragglers' early levels are not counted twice, the second call says who is still unfinished."""
+    from owlraytracing_amd.distributed import ShardedTrueKNN
+    a = {"total_intersections": 1000, "total_active_rounds": 300, "node_tests": 50, "point_tests": 70, "tie_rows": 2, "tie_rows_left": 0,
+         "solve_ms": 3.0, "tie_ms": 0.1, "unfinished": 7, "rounds": 3, "final_radius": 0.04, "dominant_kernel_launches": 1, "dominant_kernel_ms": 2.5}
+    b = {"total_intersections": 90, "total_active_rounds": 28, "node_tests": 5, "point_tests": 9, "tie_rows": 0, "tie_rows_left": 0,
+         "solve_ms": 0.5, "tie_ms": 0.0, "unfinished": 0, "rounds": 4, "final_radius": 0.08, "dominant_kernel_launches": 1, "dominant_kernel_ms": 0.4}
+    m = ShardedTrueKNN._merge_infos(a, b, 7 * 3)  # seven stragglers had run three levels each in the first call
+    assert m["total_intersections"] == 1090 and m["total_active_rounds"] == 300 + 28 - 21
+    assert m["unfinished"] == 0 and m["rounds"] == 4 and m["final_radius"] == 0.08 and m["solve_ms"] == 3.5
+    assert m["dominant_kernel_launches"] == 2 and abs(m["dominant_kernel_ms"] - 1.45) < 1e-12
+    both = ShardedTrueKNN._merge_infos(a, b, 0)  # interior + boundary phases: unfinished queries of both count
+    assert both["unfinished"] == 7 and both["total_active_rounds"] == 328
