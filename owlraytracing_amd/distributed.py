@@ -82,12 +82,13 @@ class _Comm:
         dist.all_gather(out, w, group=self.group)
         return torch.stack(out).to(t.device)
 
-    def exchange_rows(self, rows_per_peer, width, dtype, device, tag=None):
+    def exchange_rows(self, rows_per_peer, width, dtype, device, tag=None, counts_in=None):
         """all-to-all-v of 2-D row blocks: rows_per_peer[p] goes to rank p; returns the list of
         blocks received (index = source rank).
 
         Without ``tag``: counts first (an all-gather and a host round trip), then one batched
-        send/recv of exactly those rows.  With ``tag`` (the per-step halo exchange): ONE batched
+        send/recv of exactly those rows.  With ``counts_in`` (rows per source, known to the caller):
+        just that send/recv.  With ``tag`` (the per-step halo exchange): ONE batched
         send/recv of fixed-capacity messages whose first row carries the count -- the capacity of
         every ordered pair is what both ends remember of the pair's last exchange under that tag
         (x 1.25 + 64 rows); the first exchange under a tag, and any pair whose rows outgrow the
@@ -147,8 +148,10 @@ class _Comm:
                     out[p] = t.to(device)
             self._remember(tag, counts_in, [len(r) for r in rows_per_peer])
             return out
-        counts = torch.tensor([len(r) for r in rows_per_peer], dtype=torch.int64, device=device)
-        counts_in = self.all_gather(counts)[:, self.rank].tolist()  # [src] rows coming from src
+        if counts_in is None:
+            counts = torch.tensor([len(r) for r in rows_per_peer], dtype=torch.int64, device=device)
+            counts_in = self.all_gather(counts)[:, self.rank].tolist()  # [src] rows coming from src
+        # (else: the caller knows what arrives -- the answers to rows it has sent, say -- and no count travels)
         recv = [torch.empty((int(c), width), dtype=dtype, device="cpu" if self.staged else device) for c in counts_in]
         ops = []
         for p in range(self.world):
@@ -547,12 +550,17 @@ class ShardedTrueKNN:
             # copies -> owners (minimum)
             offs = np.concatenate([[0], np.cumsum(counts_in)])
             back = [lab[m + int(offs[s]): m + int(offs[s + 1])].reshape(-1, 1).contiguous() for s in range(comm.world)]
-            for p, vals in enumerate(comm.exchange_rows(back, 1, torch.int64, dev)):
+            # (both directions answer rows that travelled before: every count is known at both ends, none is exchanged)
+            expect_back = [int(len(sent_local[p])) for p in range(comm.world)]
+            expect_back[comm.rank] = int(len(back[comm.rank]))
+            for p, vals in enumerate(comm.exchange_rows(back, 1, torch.int64, dev, counts_in=expect_back)):
                 if p != comm.rank and len(vals):
                     lab[:m].scatter_reduce_(0, sent_local[p], vals.flatten(), "amin")
             # owners -> copies
             fwd = [lab[:m][sent_local[p]].reshape(-1, 1).contiguous() for p in range(comm.world)]
-            new = comm.exchange_rows(fwd, 1, torch.int64, dev)
+            expect_fwd = [int(c) for c in counts_in]
+            expect_fwd[comm.rank] = int(len(fwd[comm.rank]))
+            new = comm.exchange_rows(fwd, 1, torch.int64, dev, counts_in=expect_fwd)
             new[comm.rank] = new[comm.rank][:0]
             if len(halo):
                 lab[m:] = torch.cat(new, dim=0).flatten()
