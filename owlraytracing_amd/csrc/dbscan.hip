@@ -63,6 +63,11 @@ struct DbArgs {
   int chunk;  // packets per chunk dealt to an XCD (db_group_union_kernel)
   int scan_budget;  // steps the quick scan of a probe may take before the subtrees are asked (db_group_union_kernel)
   float reach, near_lo2, near_hi2;  // this pass of db_group_union_kernel: groups whose nearest faces are near_lo2 < d^2 <= near_hi2 apart, reach >= sqrt(near_hi2)
+  // second pass of db_group_union_kernel: uni[node] >= 0: every core point under the node is in the set that slot was the root
+  // of when the first pass had ended (db_uniform_kernel); negative: not known to be one set
+  const int32_t *split_owner;  // Lbvh::split_owner_device()
+  int32_t *uni;       // per internal node
+  int32_t *uni_leaf;  // per sorted slot, written for the listed groups that are single points only
   unsigned long long *diag_out;  // diagnostic library, TKNN_DB_DIAG & 512: the group-union kernel's wave time by part ([0] loads [1] tests [2] settles [3] pushes [4] packet set-up, s_memtime ticks) and [5] rounds [6] settles [7] packets
   int diag;  // TKNN_DB_DIAG, diagnostic library only (results are wrong when set): 1 = no probes, 2 = no unions between groups, 4 = none inside groups, 8 = walk lengths on stderr, 16 = report a stack overflow (the result is right: the call falls back), 32 = probes by scanning only (the result is right)
 };
@@ -210,17 +215,6 @@ __device__ __forceinline__ void for_each_core_group(const DbArgs &a, const LbvhP
   }
 }
 
-// the wave's flagged lanes take consecutive places of a list (one atomic per wave)
-__device__ __forceinline__ void db_append(bool flag, int32_t value, int32_t *list, unsigned long long *count) {
-  const unsigned long long m = __ballot(flag);
-  if (!m) return;
-  const int lane = threadIdx.x & 63, first = __ffsll((long long)m) - 1;
-  unsigned long long base = 0;
-  if (lane == first) base = atomicAdd(count, (unsigned long long)__popcll(m));
-  base = __shfl(base, first);
-  if (flag) list[base + __popcll(m & ((1ull << lane) - 1ull))] = value;
-}
-
 // Core flags.  Every point first looks at its GROUP, the first tight node on its own root path (db_group_kernel): its
 // points are pairwise within eps, so if it holds minPts of them the point is core without looking any further.  (Listing the
 // points that do have to look and walking for them with full waves, as the label pass does, was tried: on BASELINE config 3
@@ -342,9 +336,19 @@ __global__ void __launch_bounds__(kDbBlock) db_core_flag_kernel(DbArgs a, int32_
   const int32_t t = blockIdx.x * kDbBlock + threadIdx.x;
   if (t < a.bvh.n) flag[t] = a.core_sorted[t];
 }
-__global__ void __launch_bounds__(kDbBlock) db_core_pos_kernel(DbArgs a, const int32_t *rank, int32_t *pos) {
+// (and, if asked: the slots that are NOT core, listed in slot order for the label pass -- slot t is the (t - rank[t])-th of
+// them, no atomics -- with their number)
+__global__ void __launch_bounds__(kDbBlock) db_core_pos_kernel(DbArgs a, const int32_t *rank, int32_t *pos, int32_t *others,
+                                                               unsigned long long *n_others) {
   const int32_t t = blockIdx.x * kDbBlock + threadIdx.x;
-  if (t < a.bvh.n && a.core_sorted[t]) pos[rank[t]] = t;
+  if (t >= a.bvh.n) return;
+  const int32_t r = rank[t];
+  const bool is_core = a.core_sorted[t] != 0;
+  if (is_core)
+    pos[r] = t;
+  else if (others)
+    others[t - r] = t;
+  if (others && t == a.bvh.n - 1) *n_others = (unsigned long long)(a.bvh.n - (r + (is_core ? 1 : 0)));
 }
 __global__ void __launch_bounds__(kDbBlock) db_next_core_kernel(DbArgs a, const int32_t *rank, const int32_t *pos,
                                                                 int32_t *next_core) {
@@ -479,6 +483,58 @@ __global__ void __launch_bounds__(kDbBlock) db_group_kernel(DbArgs a, int32_t *g
     if (s <= last) out = g;
   }
   group_at[t] = out;
+}
+
+// Between the two passes of the group-union kernel: which tree nodes hold core points of ONE set only?  After the first pass
+// (pairs of groups that nearly touch) a cluster's dense part is one set, and the second pass, which walks the tree with the
+// full reach, would still go down to every group around a packet only to find it in the packet's own set.  One lane per
+// listed group climbs from the group towards the root: a parent whose other child has no core point inherits the set; at a
+// parent with two children that have some, the first to arrive leaves its set there and stops, the second goes on if both
+// sets are the same (a side that is not one set never arrives, and the parent stays "not known").  Roots do not move
+// during this kernel (no unions), so two lanes of one set see the same root.
+//   uni[node]: -1 nobody arrived; <= -2: one child arrived with set -2 - value; >= 0: one set, this root
+__global__ void __launch_bounds__(kDbBlock) db_uniform_kernel(DbArgs a, const int32_t *groups, const unsigned long long *n_groups) {
+  const LbvhView &bvh = a.bvh;
+  const long long g = (long long)blockIdx.x * kDbBlock + threadIdx.x;
+  if (g >= (long long)*n_groups) return;
+  const int32_t G = groups[g];
+  int32_t first, last, at = G;  // the subtree climbed so far: its slots, and its node (or ~slot)
+  if (G >= 0) {
+    const int32_t other = bvh.nodes[G].other;
+    first = lbvh_first(G, other), last = lbvh_last(G, other);
+  } else {
+    first = last = ~G;
+  }
+  const int32_t set = uf_find(a.parent, a.next_core[first]);
+  if (G >= 0)
+    a.uni[G] = set;
+  else
+    a.uni_leaf[first] = set;
+  const int32_t n = bvh.n;
+  while (first != 0 || last != n - 1) {
+    // parent: a left child ends where its parent splits, a right child begins right after
+    int32_t up = -1;
+    bool is_left = false;
+    if (at >= 0) {
+      is_left = at == last;
+      up = a.split_owner[is_left ? at : at - 1];
+    } else {
+      if (first < n - 1) {
+        const int32_t o = a.split_owner[first];
+        if (lbvh_first(o, bvh.nodes[o].other) == first) up = o, is_left = true;
+      }
+      if (up < 0) up = a.split_owner[first - 1];
+    }
+    const LbvhNode nd = bvh.nodes[up];
+    const int32_t up_first = lbvh_first(up, nd.other), up_last = lbvh_last(up, nd.other);
+    const int32_t sib_first = is_left ? nd.split + 1 : up_first, sib_last = is_left ? up_last : nd.split;
+    if (a.next_core[sib_first] <= sib_last) {  // the other child has core points: both must arrive, with one set
+      const int32_t old = atomicExch(a.uni + up, -2 - set);
+      if (old == -1 || -2 - old != set) break;
+    }
+    a.uni[up] = set;
+    at = up, first = up_first, last = up_last;
+  }
 }
 
 // Persistent waves, each working on one PACKET of 64 consecutive groups of the list at a time (Morton neighbours: they
@@ -623,7 +679,7 @@ __global__ void __launch_bounds__(kDbUnionBlock) __attribute__((amdgpu_waves_per
   };
   int waiting = 0;
   [[maybe_unused]] unsigned long long tm[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tm_mark = 0;
-  const bool timing = TKNN_DIAG_BUILD && (a.diag & 512);
+  const bool timing = TKNN_DIAG_BUILD && (a.diag & 512) && !((a.diag & 2048) && a.near_lo2 < 0.f) && !((a.diag & 4096) && a.near_lo2 >= 0.f);  // 2048 / 4096: the second / first pass only
 #define DB_LAP(i)                                                  \
   do {                                                             \
     if (timing) {                                                  \
@@ -733,6 +789,16 @@ __global__ void __launch_bounds__(kDbUnionBlock) __attribute__((amdgpu_waves_per
       mine = a_core;
       my_root = uf_find(a.parent, mine);
     }
+    // second pass: the one set all the packet's groups were in when the first pass had ended, if they were (the inside of
+    // a cluster): a node whose core points were all in that set (a.uni) has nothing to offer to any of them.  Both sides
+    // of the comparison are names of that moment (db_uniform_kernel) -- the roots move while this pass unites sets.
+    int32_t pk_root = -1;
+    if (a.uni) {
+      const int32_t set0 = !have ? -1 : a_ref >= 0 ? a.uni[a_ref] : a.uni_leaf[~a_ref];
+      const int32_t r0 = __builtin_amdgcn_readfirstlane(set0);
+      if (__ballot(have && set0 != r0) == 0ull) pk_root = r0;
+      if (TKNN_DIAG_BUILD && (a.diag & 1024) && lane == 0) atomicAdd(&a.diag_out[pk_root >= 0 ? 8 : 9], 1ull);
+    }
     // nothing before the packet's earliest group end can lie after any of its groups
     int32_t low = a_last;
 #pragma unroll
@@ -781,6 +847,7 @@ __global__ void __launch_bounds__(kDbUnionBlock) __attribute__((amdgpu_waves_per
       const t_f4 *src = is_node ? (const t_f4 *)(bvh.nodes + ref) : (const t_f4 *)(bvh.points + slot);
       const t_f4 v0 = src[0], v1 = src[is_node ? 1 : 0];
       const bool any_core = is_node || a.core_sorted[slot] != 0;
+      const int32_t node_set = pk_root < 0 ? -1 : is_node ? a.uni[ref] : a.uni_leaf[slot];  // (a leaf that is not core: whatever is there)
       if (valid) node_tests++;
       const int32_t split = __float_as_int(v0.w), b_other = is_node ? __float_as_int(v1.w) : slot;
       const int32_t my_end = is_node ? ref : slot;
@@ -800,7 +867,11 @@ __global__ void __launch_bounds__(kDbUnionBlock) __attribute__((amdgpu_waves_per
       for (int half = 0; half < 2; half++)
         near_packet |= (v0.x <= u_hi[half][0]) & (u_lo[half][0] <= v1.x) & (v0.y <= u_hi[half][1]) & (u_lo[half][1] <= v1.y) &
                        (v0.z <= u_hi[half][2]) & (u_lo[half][2] <= v1.z);
-      const unsigned long long m_live = __ballot(valid && any_core && b_last > low && near_packet), m_tight = __ballot(tight);
+      if (TKNN_DIAG_BUILD && (a.diag & 1024) && a.uni) {
+        const unsigned long long sk = __ballot(valid && pk_root >= 0 && node_set == pk_root), al = __ballot(valid), un = __ballot(valid && is_node && a.uni[ref] >= 0);
+        if (lane == 0) atomicAdd(&a.diag_out[10], (unsigned long long)__popcll(sk)), atomicAdd(&a.diag_out[11], (unsigned long long)__popcll(al)), atomicAdd(&a.diag_out[12], (unsigned long long)__popcll(un));
+      }
+      const unsigned long long m_live = __ballot(valid && any_core && b_last > low && near_packet && !(pk_root >= 0 && node_set == pk_root)), m_tight = __ballot(tight);
       db_wave_sync();
       DB_LAP(0);
       // lanes = groups
@@ -901,40 +972,74 @@ __global__ void __launch_bounds__(kDbBlock) db_root_kernel(DbArgs a, int32_t *is
   if (t < a.bvh.n && a.core_sorted[t] && a.parent[t] == t) is_first_row[a.min_row[t]] = 1;
 }
 
-// Labels in two launches, like the core flags: core points take their cluster's number; the others -- few, and scattered
-// over the waves -- are listed and look for the lowest-numbered cluster among their core neighbours with full waves.
-__global__ void __launch_bounds__(kDbBlock) db_label_kernel(DbArgs a, int32_t *pending, unsigned long long *n_pending) {
-  const int32_t t = blockIdx.x * kDbBlock + threadIdx.x;
-  bool walk = false;
-  if (t < a.bvh.n) {
-    const int32_t row = a.bvh.prim_id[t];
-    const uint8_t is_core = a.core_sorted[t];
-    if (a.core) a.core[row] = is_core;
-    if (is_core)
-      a.labels[row] = a.rank[a.min_row[uf_find(a.parent, t)]];  // (mostly one step: db_flatten_kernel has pointed the slots at their roots)
-    else
-      walk = true;
-  }
-  db_append(walk, t, pending, n_pending);
-}
-__global__ void __launch_bounds__(kDbBlock) db_label_walk_kernel(DbArgs a, const int32_t *pending, const unsigned long long *n_pending) {
+// The points that are not core (few -- BASELINE config 3: 0.13 % --, scattered over the waves, listed in slot order since the
+// core flags were known: db_core_pos_kernel) take the lowest-numbered cluster among their core neighbours.  Finding those
+// neighbours needs the core flags only, not the clusters: the walks -- chains of dependent loads by a few hundred waves, 0.25 ms
+// on config 3 -- run BESIDE the group unions on a stream of their own and leave, per listed point, the core neighbours they met
+// (one per tight node, db for_each_core_group; a point that is not core has fewer than minPts - 1 of them: `per` - 1 places, and
+// a count of -1 if that should ever not be enough).  Lists that would not fit the room (`capacity` words; a set that is mostly
+// noise) are not written: the label kernel then walks itself, as it does for a count of -1.
+__global__ void __launch_bounds__(kDbBlock) db_border_walk_kernel(DbArgs a, const int32_t *pending, const unsigned long long *n_pending, int32_t *lists,
+                                                                  int per, long long capacity) {
   __shared__ unsigned long long blk_stats[2];
   if (threadIdx.x < 2) blk_stats[threadIdx.x] = 0ull;
   __syncthreads();
   uint32_t node_tests = 0, point_tests = 0;
   const long long total = (long long)*n_pending;
-  for (long long i = (long long)blockIdx.x * kDbBlock + threadIdx.x; i < total; i += (long long)gridDim.x * kDbBlock) {
-    const int32_t t = pending[i];
-    const LbvhPoint q = a.bvh.points[t];
-    int32_t first_row = -1;  // of my cluster: the smallest over the clusters of my core neighbours (the lowest label)
-    for_each_core_group(
-        a, q, -1, [](int32_t) { return false; },
-        [&](int32_t other) {
-          const int32_t m = a.min_row[uf_find(a.parent, other)];
-          if (first_row < 0 || m < first_row) first_row = m;
-        },
-        node_tests, point_tests);
-    a.labels[a.bvh.prim_id[t]] = first_row < 0 ? -1 : a.rank[first_row];
+  if (total * per <= capacity) {
+    for (long long i = (long long)blockIdx.x * kDbBlock + threadIdx.x; i < total; i += (long long)gridDim.x * kDbBlock) {
+      const LbvhPoint q = a.bvh.points[pending[i]];
+      int32_t *mine = lists + i * per;
+      int32_t cnt = 0;
+      for_each_core_group(
+          a, q, -1, [](int32_t) { return false; },
+          [&](int32_t other) {
+            if (cnt < per - 1) mine[1 + cnt] = other;
+            cnt++;
+          },
+          node_tests, point_tests);
+      mine[0] = cnt <= per - 1 ? cnt : -1;
+    }
+  }
+  db_add_stats(a.stats + 4, blk_stats, node_tests, point_tests);
+}
+
+// Labels: core points take their cluster's number (and every point's core flag goes to its row); the listed points take the
+// smallest number among the core neighbours db_border_walk_kernel has left them (or walk now).  ONE launch: the first
+// `walk_blocks` workgroups serve the list (grid-stride), the rest stream -- two scattered stores per point.
+__global__ void __launch_bounds__(kDbBlock) db_label_kernel(DbArgs a, const int32_t *pending, const unsigned long long *n_pending, int walk_blocks,
+                                                            const int32_t *lists, int per, long long capacity) {
+  __shared__ unsigned long long blk_stats[2];
+  if (threadIdx.x < 2) blk_stats[threadIdx.x] = 0ull;
+  __syncthreads();
+  uint32_t node_tests = 0, point_tests = 0;
+  if ((int)blockIdx.x >= walk_blocks) {
+    const long long t = (long long)(blockIdx.x - walk_blocks) * kDbBlock + threadIdx.x;
+    if (t < a.bvh.n) {
+      const int32_t row = a.bvh.prim_id[t];
+      const uint8_t is_core = a.core_sorted[t];
+      if (a.core) a.core[row] = is_core;
+      if (is_core) a.labels[row] = a.rank[a.min_row[uf_find(a.parent, (int32_t)t)]];  // (mostly one step: db_flatten_kernel has pointed the slots at their roots)
+    }
+  } else {
+    const long long total = (long long)*n_pending;
+    const bool listed = lists != nullptr && total * per <= capacity;
+    for (long long i = (long long)blockIdx.x * kDbBlock + threadIdx.x; i < total; i += (long long)walk_blocks * kDbBlock) {
+      const int32_t t = pending[i];
+      int32_t first_row = -1;  // of my cluster: the smallest over the clusters of my core neighbours (the lowest label)
+      auto take = [&](int32_t other) {
+        const int32_t m = a.min_row[uf_find(a.parent, other)];
+        if (first_row < 0 || m < first_row) first_row = m;
+      };
+      const int32_t cnt = listed ? lists[i * per] : -1;
+      if (cnt >= 0) {
+        for (int32_t j = 0; j < cnt; j++) take(lists[i * per + 1 + j]);
+      } else {
+        const LbvhPoint q = a.bvh.points[t];
+        for_each_core_group(a, q, -1, [](int32_t) { return false; }, take, node_tests, point_tests);
+      }
+      a.labels[a.bvh.prim_id[t]] = first_row < 0 ? -1 : a.rank[first_row];
+    }
   }
   db_add_stats(a.stats + 4, blk_stats, node_tests, point_tests);
 }
@@ -1107,7 +1212,7 @@ int64_t Engine::dbscan_noise(float eps, int min_pts, uint8_t *d_noise, hipStream
     hipLaunchKernelGGL(db_core_flag_kernel, dim3(blocks), dim3(kDbBlock), 0, s, a, flag);
     OWLMI_HIP(hipcub::DeviceScan::ExclusiveSum(scan_tmp, scan_bytes, flag, core_rank, (int)n, s));
     OWLMI_HIP(hipMemsetAsync(pos, 0x7f, ((size_t)n + 1) * sizeof(int32_t), s));
-    hipLaunchKernelGGL(db_core_pos_kernel, dim3(blocks), dim3(kDbBlock), 0, s, a, core_rank, pos);
+    hipLaunchKernelGGL(db_core_pos_kernel, dim3(blocks), dim3(kDbBlock), 0, s, a, core_rank, pos, (int32_t *)nullptr, (unsigned long long *)nullptr);
     hipLaunchKernelGGL(db_next_core_kernel, dim3(blocks1), dim3(kDbBlock), 0, s, a, core_rank, pos, next_core);
   }
   hipLaunchKernelGGL(db_noise_probe_kernel, dim3(blocks), dim3(kDbBlock), 0, s, a, noise, 1);
@@ -1122,7 +1227,7 @@ void Engine::dbscan(float eps, int min_pts, int32_t *d_labels, uint8_t *d_core, 
   const int64_t n = bvh_.size();
   // scratch: core flags per slot, parent, root flags, ranks, next_core (+ two sentinels), smallest rows
   const size_t min_row_at = ((size_t)n * 17 + 8 + 15) / 16 * 16;
-  const size_t need = (min_row_at + (size_t)n * 4 + 255) / 256 * 256;
+  const size_t need = (min_row_at + (size_t)n * 12 + 255) / 256 * 256;  // ... the list of the slots that are not core, their core neighbours
   size_t scan_bytes = 0, select_bytes = 0;
   OWLMI_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, (int32_t *)nullptr, (int32_t *)nullptr, (int)n, s));
   OWLMI_HIP(hipcub::DeviceSelect::If(nullptr, select_bytes, (int32_t *)nullptr, (int32_t *)nullptr, (unsigned long long *)nullptr, (int)n, DbIsGroup(), s));
@@ -1149,6 +1254,15 @@ void Engine::dbscan(float eps, int min_pts, int32_t *d_labels, uint8_t *d_core, 
   int32_t *next_core = (int32_t *)(ws + (size_t)n * 12 + 4);  // n + 1 entries
   a.core_sorted = (uint8_t *)(ws + (size_t)n * 16 + 8);
   a.min_row = (int32_t *)(ws + min_row_at);
+  int32_t *not_core = a.min_row + n;  // in slot order; its length in counters_[19]
+  int32_t *border_lists = not_core + n;  // `border_per` words per listed point, if they fit n words: a count and the core neighbours
+  const int border_per = std::max(2, min_pts);
+  const bool side = !core_label && !(getenv("TKNN_DB_SIDE") && atoi(getenv("TKNN_DB_SIDE")) == 0);  // (0: measurements without the side stream)
+  if (side && !db_side_) {
+    OWLMI_HIP(hipStreamCreateWithFlags(&db_side_, hipStreamNonBlocking));
+    OWLMI_HIP(hipEventCreateWithFlags(&ev_side_a_, hipEventDisableTiming));
+    OWLMI_HIP(hipEventCreateWithFlags(&ev_side_b_, hipEventDisableTiming));
+  }
   a.next_core = next_core;
   a.eps_in2 = eps * eps * (1.0f - 1e-5f);
   a.eps_out2 = eps * eps * (1.0f + 1e-5f);
@@ -1185,8 +1299,14 @@ void Engine::dbscan(float eps, int min_pts, int32_t *d_labels, uint8_t *d_core, 
     hipLaunchKernelGGL(db_core_flag_kernel, dim3(blocks), dim3(kDbBlock), 0, s, a, flag);
     OWLMI_HIP(hipcub::DeviceScan::ExclusiveSum(scan_tmp, scan_bytes, flag, core_rank, (int)n, s));
     OWLMI_HIP(hipMemsetAsync(pos, 0x7f, ((size_t)n + 1) * sizeof(int32_t), s));  // 0x7f7f7f7f: "none", clamped below
-    hipLaunchKernelGGL(db_core_pos_kernel, dim3(blocks), dim3(kDbBlock), 0, s, a, core_rank, pos);
+    hipLaunchKernelGGL(db_core_pos_kernel, dim3(blocks), dim3(kDbBlock), 0, s, a, core_rank, pos, core_label ? (int32_t *)nullptr : not_core, counters_ + 19);
     hipLaunchKernelGGL(db_next_core_kernel, dim3(blocks1), dim3(kDbBlock), 0, s, a, core_rank, pos, next_core);
+  }
+  if (side) {  // the walks of the points that are not core, beside everything up to the label kernel
+    OWLMI_HIP(hipEventRecord(ev_side_a_, s));
+    OWLMI_HIP(hipStreamWaitEvent(db_side_, ev_side_a_, 0));
+    hipLaunchKernelGGL(db_border_walk_kernel, dim3(walk_grid), dim3(kDbBlock), 0, db_side_, a, not_core, counters_ + 19, border_lists, border_per, (long long)n);
+    OWLMI_HIP(hipEventRecord(ev_side_b_, db_side_));
   }
   if (core_label) {
     hipLaunchKernelGGL(db_assign_kernel, dim3(blocks), dim3(kDbBlock), 0, s, a, core_label);
@@ -1254,6 +1374,14 @@ void Engine::dbscan(float eps, int min_pts, int32_t *d_labels, uint8_t *d_core, 
       hipLaunchKernelGGL(db_group_union_kernel, dim3(grid), dim3(kDbUnionBlock), 0, s, a, groups, n_groups, n_groups + 1, n_groups + 9);
       OWLMI_HIP(hipMemsetAsync(n_groups + 1, 0, 8 * sizeof(unsigned long long), s));
       a.near_lo2 = a.near_hi2;
+      if (n > 1 && !(getenv("TKNN_DB_UNIFORM") && atoi(getenv("TKNN_DB_UNIFORM")) == 0)) {  // (0: measurements without it)
+        // which nodes hold one set only, now that the groups that touch are united (min_row's place is free until the unions are done)
+        a.uni = a.min_row;
+        a.uni_leaf = a.rank;  // (the select has used the per-slot group references up)
+        a.split_owner = bvh_.split_owner_device();
+        OWLMI_HIP(hipMemsetAsync(a.uni, 0xff, (size_t)n * sizeof(int32_t), s));
+        hipLaunchKernelGGL(db_uniform_kernel, dim3(blocks), dim3(kDbBlock), 0, s, a, groups, n_groups);
+      }
     }
     a.near_hi2 = a.eps_out2;
     a.reach = db_reach_of(a.near_hi2);
@@ -1266,17 +1394,19 @@ void Engine::dbscan(float eps, int min_pts, int32_t *d_labels, uint8_t *d_core, 
   hipLaunchKernelGGL(db_root_kernel, dim3(blocks), dim3(kDbBlock), 0, s, a, is_root);
   OWLMI_HIP(hipGetLastError());
   OWLMI_HIP(hipcub::DeviceScan::ExclusiveSum(scan_tmp, scan_bytes, is_root, a.rank, (int)n, s));
-  // number of clusters = rank[n-1] + is_root[n-1] (read now: the flags' place is the label pass's list next)
+  // number of clusters = rank[n-1] + is_root[n-1]
   int32_t last[2] = {0, 0};
   OWLMI_HIP(hipMemcpyAsync(&last[0], a.rank + (n - 1), 4, hipMemcpyDeviceToHost, s));
   OWLMI_HIP(hipMemcpyAsync(&last[1], is_root + (n - 1), 4, hipMemcpyDeviceToHost, s));
   OWLMI_HIP(hipEventRecord(ev_f_, s));
-  hipLaunchKernelGGL(db_label_kernel, dim3(blocks), dim3(kDbBlock), 0, s, a, is_root, counters_ + 19);
-  hipLaunchKernelGGL(db_label_walk_kernel, dim3(walk_grid), dim3(kDbBlock), 0, s, a, is_root, counters_ + 19);
+  if (side) OWLMI_HIP(hipStreamWaitEvent(s, ev_side_b_, 0));
+  hipLaunchKernelGGL(db_label_kernel, dim3(walk_grid + blocks), dim3(kDbBlock), 0, s, a, not_core, counters_ + 19, (int)walk_grid,
+                     side ? border_lists : (const int32_t *)nullptr, border_per, (long long)n);
   OWLMI_HIP(hipGetLastError());
   OWLMI_HIP(hipEventRecord(e1, s));
   OWLMI_HIP(hipMemcpyAsync(h_counters_ + 8, counters_ + 8, sizeof(unsigned long long), hipMemcpyDeviceToHost, s));   // groups
   OWLMI_HIP(hipMemcpyAsync(h_counters_ + 9, counters_ + 17, sizeof(unsigned long long), hipMemcpyDeviceToHost, s));  // stack overflows
+  OWLMI_HIP(hipMemcpyAsync(h_counters_ + 10, counters_ + 19, sizeof(unsigned long long), hipMemcpyDeviceToHost, s));  // slots that are not core
   db_read_stats(s);
   OWLMI_HIP(hipStreamSynchronize(s));
   if (!per_point && h_counters_[9] != 0 && !db_force_point_) {
@@ -1314,6 +1444,14 @@ void Engine::dbscan(float eps, int min_pts, int32_t *d_labels, uint8_t *d_core, 
       const double tot = (double)(t[0] + t[1] + t[2] + t[3] + t[4]);
       std::fprintf(stderr, "[dbscan] union kernel wave time: loads %.1f%%  tests %.1f%%  settles %.1f%%  pushes %.1f%%  packet set-up %.1f%%;  %.1f rounds and %.1f settles per packet, %llu packet walks, %.1f us per packet walk (s_memtime at 100 MHz)\n",
                    100 * t[0] / tot, 100 * t[1] / tot, 100 * t[2] / tot, 100 * t[3] / tot, 100 * t[4] / tot, (double)t[5] / (double)t[7], (double)t[6] / (double)t[7], t[7], tot / 100.0 / (double)t[7]);
+    }
+    if (getenv("TKNN_DB_VERBOSE"))
+      std::fprintf(stderr, "[dbscan] node / point tests: core flags %llu / %llu, unions %llu / %llu, labels %llu / %llu; %llu slots not core\n", h_counters_[0],
+                   h_counters_[1], h_counters_[2], h_counters_[3], h_counters_[4], h_counters_[5], h_counters_[10]);
+    if (a.diag & 1024) {
+      unsigned long long t[5];
+      OWLMI_HIP(hipMemcpy(t, counters_ + 28, sizeof t, hipMemcpyDeviceToHost));
+      std::fprintf(stderr, "[dbscan] second union pass: %llu packets of one set, %llu mixed; %llu nodes popped, %llu of them dropped as the packet's own set, %llu known to be of one set\n", t[0], t[1], t[3], t[2], t[4]);
     }
     if (a.diag & 8)
       std::fprintf(stderr, "[dbscan] groups %llu  union-phase node tests %llu  longest walk %llu  mean of the waves' longest %.0f\n", h_counters_[8],
@@ -1374,7 +1512,7 @@ void Engine::dbscan_auto(float eps0, int min_pts, double max_noise, int max_roun
       hipLaunchKernelGGL(db_core_flag_kernel, dim3(blocks), dim3(kDbBlock), 0, s, a, flag);
       OWLMI_HIP(hipcub::DeviceScan::ExclusiveSum(scan_tmp, scan_bytes, flag, core_rank, (int)n, s));
       OWLMI_HIP(hipMemsetAsync(pos, 0x7f, ((size_t)n + 1) * sizeof(int32_t), s));
-      hipLaunchKernelGGL(db_core_pos_kernel, dim3(blocks), dim3(kDbBlock), 0, s, a, core_rank, pos);
+      hipLaunchKernelGGL(db_core_pos_kernel, dim3(blocks), dim3(kDbBlock), 0, s, a, core_rank, pos, (int32_t *)nullptr, (unsigned long long *)nullptr);
       hipLaunchKernelGGL(db_next_core_kernel, dim3(blocks1), dim3(kDbBlock), 0, s, a, core_rank, pos, next_core);
     }
     hipLaunchKernelGGL(db_noise_probe_kernel, dim3(blocks), dim3(kDbBlock), 0, s, a, noise, t == 0 ? 1 : 0);

@@ -50,6 +50,10 @@ class Lbvh {
   const float *scene_device() const { return scene_; }  // 6 floats: lo xyz, hi xyz of the built set
   // device counter behind the scene box: points with a NaN coordinate (they sort last)
   int32_t *nan_count() const { return reinterpret_cast<int32_t *>(scene_ + 6); }
+  // split_owner[s] = the internal node that splits its range after sorted position s (n - 1 entries): a node's parent in O(1)
+  // -- internal node i is a left child iff it is its range's LAST position (parent = split_owner[i]), else a right child
+  // (parent = split_owner[i - 1]); valid as long as the tree is
+  const int32_t *split_owner_device() const { return split_owner_; }
   int64_t size() const { return n_; }
   bool built() const { return built_; }
   void clear() { built_ = false; }  // marks the tree unusable (a failed rebuild); memory stays reserved

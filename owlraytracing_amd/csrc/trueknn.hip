@@ -306,6 +306,9 @@ Engine::~Engine() {
   if (ev_d_) (void)hipEventDestroy(ev_d_);
   if (ev_e_) (void)hipEventDestroy(ev_e_);
   if (ev_f_) (void)hipEventDestroy(ev_f_);
+  if (ev_side_a_) (void)hipEventDestroy(ev_side_a_);
+  if (ev_side_b_) (void)hipEventDestroy(ev_side_b_);
+  if (db_side_) (void)hipStreamDestroy(db_side_);
 }
 
 void Engine::set_halo(const float *d_xyz, const int32_t *d_ids, int64_t m, hipStream_t s) {

@@ -116,6 +116,9 @@ class Engine {
   unsigned long long *halo_mask_ = nullptr;  // per leaf block: peers it may have points for (+ 64 cursors)
   int64_t halo_mask_cap_ = 0;
   hipEvent_t ev_a_ = nullptr, ev_b_ = nullptr, ev_c_ = nullptr, ev_d_ = nullptr, ev_e_ = nullptr, ev_f_ = nullptr;
+  // dbscan(): the walks of the points that are not core run beside the group unions on a stream of their own
+  hipStream_t db_side_ = nullptr;
+  hipEvent_t ev_side_a_ = nullptr, ev_side_b_ = nullptr;
   // the packet kernel's solve launches the tie pass behind itself, before its one host round trip: set if
   // that launch has seen every flagged row (no tail ran, the list held them all)
   bool ties_early_ = false;

@@ -20,6 +20,6 @@ for _ in range(reps):
     i = eng.dbscan(0.01, 4)["info"]
     if best is None or i["solve_ms"] < best["solve_ms"]:
         best = i
-print("lib %s: clusters %d  whole %.2f ms  core %.2f  union %.2f  label %.2f  (nodes %d points %d)" % (
+print("lib %s: clusters %d  whole %.2f ms  core %.2f  union %.2f  label %.2f  (nodes %d points %d; unions: nodes %d points %d)" % (
     os.path.basename(os.environ.get("OWL_MI355X_LIB", "default")), best["clusters"], best["solve_ms"], best["core_ms"], best["union_ms"], best["label_ms"],
-    best["node_tests"], best["point_tests"]), flush=True)
+    best["node_tests"], best["point_tests"], best.get("union_node_tests", -1), best.get("union_point_tests", -1)), flush=True)
