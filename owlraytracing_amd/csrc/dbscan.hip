@@ -60,6 +60,7 @@ struct DbArgs {
   unsigned long long *stats;
   int32_t *group_of;  // per sorted slot, written by the core-flag kernel (see db_group_kernel); null: not wanted
   int32_t *near_node;  // per sorted slot, or null: the node a few levels above the point's group (written by the core-flag kernel for the noise probe)
+  int short_way;  // db_group_union_kernel's settle: 0: the long way only (measurements)
   int chunk;  // packets per chunk dealt to an XCD (db_group_union_kernel)
   int scan_budget;  // steps the quick scan of a probe may take before the subtrees are asked (db_group_union_kernel)
   float reach, near_lo2, near_hi2;  // this pass of db_group_union_kernel: groups whose nearest faces are near_lo2 < d^2 <= near_hi2 apart, reach >= sqrt(near_hi2)
@@ -91,6 +92,20 @@ __device__ __forceinline__ void db_add_stats(unsigned long long *stats, unsigned
   if (threadIdx.x == 0) {
     atomicAdd(&stats[0], blk[0]);
     atomicAdd(&stats[1], blk[1]);
+  }
+}
+
+// the same for a kernel whose waves are independent and whose LDS is counted in waves per CU: one global atomic per wave
+__device__ __forceinline__ void db_add_stats_wave(unsigned long long *stats, uint32_t nodes, uint32_t points) {
+  stats += ((blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) & (kDbStripes - 1)) * 8;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    nodes += __shfl_xor(nodes, off);
+    points += __shfl_xor(points, off);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    atomicAdd(&stats[0], (unsigned long long)nodes);
+    atomicAdd(&stats[1], (unsigned long long)points);
   }
 }
 
@@ -332,10 +347,11 @@ __global__ void __launch_bounds__(kDbBlock) db_core_kernel(DbArgs a) {
 
 // next_core[s] = first core slot >= s (n if none): with rank[s] = number of core slots before s (an
 // exclusive sum of the flags) and pos[r] = slot of the r-th core point, next_core[s] = pos[rank[s]]
-__global__ void __launch_bounds__(kDbBlock) db_core_flag_kernel(DbArgs a, int32_t *flag) {
-  const int32_t t = blockIdx.x * kDbBlock + threadIdx.x;
-  if (t < a.bvh.n) flag[t] = a.core_sorted[t];
-}
+// (the flags are summed as they are read: one byte per slot in, one word out)
+struct DbFlagOf {
+  __host__ __device__ int32_t operator()(uint8_t c) const { return c; }
+};
+typedef hipcub::TransformInputIterator<int32_t, DbFlagOf, const uint8_t *> DbFlagIter;
 // (and, if asked: the slots that are NOT core, listed in slot order for the label pass -- slot t is the (t - rank[t])-th of
 // them, no atomics -- with their number)
 __global__ void __launch_bounds__(kDbBlock) db_core_pos_kernel(DbArgs a, const int32_t *rank, int32_t *pos, int32_t *others,
@@ -348,7 +364,11 @@ __global__ void __launch_bounds__(kDbBlock) db_core_pos_kernel(DbArgs a, const i
     pos[r] = t;
   else if (others)
     others[t - r] = t;
-  if (others && t == a.bvh.n - 1) *n_others = (unsigned long long)(a.bvh.n - (r + (is_core ? 1 : 0)));
+  if (t == a.bvh.n - 1) {
+    const int32_t n_core = r + (is_core ? 1 : 0);
+    pos[n_core] = 0x7f7f7f7f;  // "none" (clamped by db_next_core_kernel): the one place a slot behind the last core point looks at
+    if (others) *n_others = (unsigned long long)(a.bvh.n - n_core);
+  }
 }
 __global__ void __launch_bounds__(kDbBlock) db_next_core_kernel(DbArgs a, const int32_t *rank, const int32_t *pos,
                                                                 int32_t *next_core) {
@@ -554,6 +574,10 @@ __global__ void __launch_bounds__(kDbBlock) db_uniform_kernel(DbArgs a, const in
 // the stack walk needs some 40 rounds of loads per packet; with the popped nodes tested against the packet's bounding box
 // instead of its 64 groups, a packet across a jump of the Z-curve walked half the tree: one wave, 4 ms.)
 constexpr int kDbBuf = 8;
+#ifndef TKNN_DB_BOXES
+#define TKNN_DB_BOXES 2
+#endif
+constexpr int kDbBoxes = TKNN_DB_BOXES;  // bounding boxes per packet for the prefilter of popped nodes (64 / kDbBoxes lanes each)
 #ifndef TKNN_DB_UNION_BLOCK
 #define TKNN_DB_UNION_BLOCK 128  // threads per workgroup of the group-union kernel (its waves are independent)
 #define TKNN_DB_WAVES 5          // waves per SIMD its register allocation aims at
@@ -577,15 +601,12 @@ __device__ __forceinline__ void db_wave_sync() {
 }
 __global__ void __launch_bounds__(kDbUnionBlock) __attribute__((amdgpu_waves_per_eu(TKNN_DB_WAVES))) db_group_union_kernel(DbArgs a, const int32_t *groups, const unsigned long long *n_groups,
                                                                   unsigned long long *next_packet, unsigned long long *overflow) {
-  __shared__ unsigned long long blk_stats[2];
   __shared__ int32_t buf_ref[kDbBuf * kDbUnionBlock];    // [entry][thread]: the group's node (or ~slot of a single point)
   __shared__ int32_t buf_other[kDbBuf * kDbUnionBlock];  // the other end of its slot range | far-corners-within-eps << 31
   __shared__ int32_t stack_all[(kDbUnionBlock / 64) * kDbStack];
   __shared__ __align__(16) DbCand cand_all[(kDbUnionBlock / 64) * kDbCand];
   int32_t *stack = stack_all + (threadIdx.x >> 6) * kDbStack;
   DbCand *cand = cand_all + (threadIdx.x >> 6) * kDbCand;
-  if (threadIdx.x < 2) blk_stats[threadIdx.x] = 0ull;
-  __syncthreads();
   const LbvhView &bvh = a.bvh;
   uint32_t node_tests = 0, point_tests = 0;
   if ((a.diag & 16) && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(overflow, 1ull);  // diagnostic library: take the host's fallback
@@ -678,6 +699,7 @@ __global__ void __launch_bounds__(kDbUnionBlock) __attribute__((amdgpu_waves_per
     return 0;
   };
   int waiting = 0;
+  [[maybe_unused]] uint32_t pk_long = 0;  // (timing) entries of this packet that went the long way, over the lanes: summed at the end
   [[maybe_unused]] unsigned long long tm[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tm_mark = 0;
   const bool timing = TKNN_DIAG_BUILD && (a.diag & 512) && !((a.diag & 2048) && a.near_lo2 < 0.f) && !((a.diag & 4096) && a.near_lo2 >= 0.f);  // 2048 / 4096: the second / first pass only
 #define DB_LAP(i)                                                  \
@@ -692,32 +714,68 @@ __global__ void __launch_bounds__(kDbUnionBlock) __attribute__((amdgpu_waves_per
   auto settle = [&]() {
     DB_LAP(1);
     if (timing) tm[6]++;
-    int32_t b_core[kDbBuf], b_last[kDbBuf], par[kDbBuf];
+    // (every load of a round is issued whether its entry exists or not, from a place that does: a load under a condition is
+    // waited for before the next one is issued -- eight round trips to memory instead of one)
+    int32_t b_core[kDbBuf], b_last[kDbBuf], par[kDbBuf], at[kDbBuf];
 #pragma unroll
     for (int w = 0; w < kDbBuf; w++) {
-      b_core[w] = 0x7fffffff;
-      b_last[w] = -1;
-      if (w < waiting) {
-        const int32_t x = my_ref[w * kDbUnionBlock], o = my_other[w * kDbUnionBlock] & 0x7fffffff;
-        const int32_t end = x >= 0 ? x : ~x;
-        b_last[w] = max(end, o);
-        b_core[w] = a.next_core[min(end, o)];
+      const int32_t x = my_ref[w * kDbUnionBlock], o = my_other[w * kDbUnionBlock] & 0x7fffffff;
+      const int32_t end = x >= 0 ? x : ~x;
+      const bool is = w < waiting;
+      b_last[w] = is ? max(end, o) : -1;
+      at[w] = is ? min(end, o) : 0;
+    }
+#pragma unroll
+    for (int w = 0; w < kDbBuf; w++) b_core[w] = a.next_core[at[w]];
+#pragma unroll
+    for (int w = 0; w < kDbBuf; w++) {
+      if (!(w < waiting)) b_core[w] = 0x7fffffff;
+      at[w] = b_core[w] <= b_last[w] ? b_core[w] : 0;
+    }
+#pragma unroll
+    for (int w = 0; w < kDbBuf; w++) par[w] = uf_load(a.parent + at[w]);
+    const int32_t my_up = uf_load(a.parent + my_root);  // (my root may have been hooked under another since I last looked)
+#pragma unroll
+    for (int w = 0; w < kDbBuf; w++) at[w] = par[w];  // >= 0: parents of places that exist
+    // a third round: the parents' parents -- with path halving a slot is rarely more than two steps below its root, and a
+    // group whose ROOT is mine needs no look at all (most of what a lane collects in the second pass, where the sets have
+    // grown together but the first core slots still point at roots of the first pass)
+#pragma unroll
+    for (int w = 0; w < kDbBuf; w++) par[w] = uf_load(a.parent + at[w]);
+    if (my_up != my_root) my_root = uf_find(a.parent, my_up);
+    uint32_t todo = 0;  // collected groups that have a core point and are not in my set as far as these loads can tell
+#pragma unroll
+    for (int w = 0; w < kDbBuf; w++) {
+      if (!(b_core[w] <= b_last[w])) continue;  // no core point in it (or no entry)
+      if (par[w] != at[w]) par[w] = uf_find(a.parent, par[w]);  // (more than two steps: the chain, rarely)
+      if (par[w] != my_root) todo |= 1u << w;  // par[w]: the group's root
+    }
+    if (a.diag & 2) todo = 0;
+    // The short way first: if the farthest corners are within eps the edge is known, and one compare-and-swap hooks the
+    // larger root under the smaller.  (A root read here may be hooked under another by a different wave by now: the swap then
+    // fails, or hooks under a slot that is no root any more but IS in my set; the first is left to the long way below, the
+    // second is fine.)  Tried and dropped: deciding the other pairs here too by ONE distance, first core point against first
+    // core point -- in the first pass that is an edge for half of them, and the pass got 0.3 ms SLOWER (2.13 against 1.82 ms
+    // for both).
+#pragma unroll
+    for (int w = 0; w < kDbBuf; w++) {
+      if (!(todo & (1u << w)) || !a.short_way || my_other[w * kDbUnionBlock] >= 0) continue;
+      const int32_t ro = par[w];
+      if (ro == my_root) {  // (joined by an earlier entry of this very loop)
+        todo &= ~(1u << w);
+        continue;
+      }
+      const int32_t lo = min(ro, my_root), hi = max(ro, my_root);
+      if (atomicCAS(a.parent + hi, hi, lo) == hi) {
+        todo &= ~(1u << w);
+        my_root = lo;
       }
     }
-#pragma unroll
-    for (int w = 0; w < kDbBuf; w++) {
-      par[w] = -1;
-      if (b_core[w] <= b_last[w]) par[w] = uf_load(a.parent + b_core[w]);  // else: no core point in it (or no entry)
-    }
-    uint32_t todo = 0;  // collected groups that have a core point and do not point at my root
-#pragma unroll
-    for (int w = 0; w < kDbBuf; w++)
-      if (b_core[w] <= b_last[w] && par[w] != my_root) todo |= 1u << w;  // (a parent pointer never leaves its set: pointing at my root means "in my set")
-    if (a.diag & 2) todo = 0;
     // the rest one after the other (not unrolled: the probe's private stack would be kept once per copy)
     while (todo) {
       const int w = __ffs((int)todo) - 1;
       todo &= todo - 1u;
+      if (timing) pk_long++;
       const int32_t B = my_ref[w * kDbUnionBlock], packed = my_other[w * kDbUnionBlock];
       const int32_t end = B >= 0 ? B : ~B, o = packed & 0x7fffffff;
       const int32_t other_last = max(end, o), other = a.next_core[min(end, o)];  // its first core slot stands for the group
@@ -749,6 +807,7 @@ __global__ void __launch_bounds__(kDbUnionBlock) __attribute__((amdgpu_waves_per
     DB_LAP(2);
   };
   if (timing) tm_mark = __builtin_amdgcn_s_memtime();
+  [[maybe_unused]] const unsigned long long wave_t0 = tm_mark;
   for (;;) {
     // ---- take a packet.  Each XCD has its own L2: the list is dealt to the XCDs in chunks of packets, a wave takes from
     // the chunks of the XCD it runs on and from the others' when those are used up.
@@ -766,6 +825,10 @@ __global__ void __launch_bounds__(kDbUnionBlock) __attribute__((amdgpu_waves_per
         seg_empty |= 1u << from;  // places only grow: this XCD's chunks are used up
     }
     if (packet < 0) break;
+    [[maybe_unused]] const unsigned long long packet_t0 = timing ? __builtin_amdgcn_s_memtime() : 0ull;
+    [[maybe_unused]] const unsigned long long pk_rounds0 = tm[5], pk_settles0 = tm[6], pk_settle_t0 = tm[2];
+    [[maybe_unused]] const uint32_t pk_points0 = point_tests;
+    pk_long = 0;
     // ---- lanes = the packet's groups
     const long long g = packet * 64 + lane;
     const bool have = g < total;
@@ -807,7 +870,7 @@ __global__ void __launch_bounds__(kDbUnionBlock) __attribute__((amdgpu_waves_per
     // a jump of the Z curve better than one), widened by the reach: a popped node that meets neither can be reached by no
     // group and is dropped where it is popped -- 64 nodes per instruction -- instead of costing a turn of the test loop
     // below, which deals with one node at a time (47 % of the kernel's wave time, half of it on nodes no group reaches).
-    float u_lo[2][3], u_hi[2][3];
+    float u_lo[kDbBoxes][3], u_hi[kDbBoxes][3];
     {
       float l[3], h[3];
       for (int c = 0; c < 3; c++) {
@@ -817,13 +880,14 @@ __global__ void __launch_bounds__(kDbUnionBlock) __attribute__((amdgpu_waves_per
         l[c] = have ? (alo[c] - r) - slack : INFINITY;
         h[c] = have ? (ahi[c] + r) + slack : -INFINITY;
 #pragma unroll
-        for (int off = 16; off > 0; off >>= 1) {
+        for (int off = 32 / kDbBoxes; off > 0; off >>= 1) {
           l[c] = fminf(l[c], __shfl_xor(l[c], off));
           h[c] = fmaxf(h[c], __shfl_xor(h[c], off));
         }
-        for (int half = 0; half < 2; half++) {
-          u_lo[half][c] = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(l[c]), 32 * half));
-          u_hi[half][c] = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(h[c]), 32 * half));
+#pragma unroll
+        for (int half = 0; half < kDbBoxes; half++) {
+          u_lo[half][c] = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(l[c]), (64 / kDbBoxes) * half));
+          u_hi[half][c] = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(h[c]), (64 / kDbBoxes) * half));
         }
       }
     }
@@ -846,8 +910,12 @@ __global__ void __launch_bounds__(kDbUnionBlock) __attribute__((amdgpu_waves_per
       const int32_t slot = is_node ? 0 : ~ref;
       const t_f4 *src = is_node ? (const t_f4 *)(bvh.nodes + ref) : (const t_f4 *)(bvh.points + slot);
       const t_f4 v0 = src[0], v1 = src[is_node ? 1 : 0];
-      const bool any_core = is_node || a.core_sorted[slot] != 0;
-      const int32_t node_set = pk_root < 0 ? -1 : is_node ? a.uni[ref] : a.uni_leaf[slot];  // (a leaf that is not core: whatever is there)
+      // (loads that only some lanes or some packets need are issued all the same, beside the boxes: under a condition they
+      // would be a second and a third round trip to memory in every round)
+      const uint8_t leaf_core = a.core_sorted[slot];
+      int32_t node_set = -1;
+      if (a.uni) node_set = (is_node ? a.uni : a.uni_leaf)[is_node ? ref : slot];  // (a leaf that is not core: whatever is there)
+      const bool any_core = is_node || leaf_core != 0;
       if (valid) node_tests++;
       const int32_t split = __float_as_int(v0.w), b_other = is_node ? __float_as_int(v1.w) : slot;
       const int32_t my_end = is_node ? ref : slot;
@@ -864,7 +932,7 @@ __global__ void __launch_bounds__(kDbUnionBlock) __attribute__((amdgpu_waves_per
       // nodes nothing can come of: past the packet's last use, a leaf that is not core, out of every group's reach
       bool near_packet = false;
 #pragma unroll
-      for (int half = 0; half < 2; half++)
+      for (int half = 0; half < kDbBoxes; half++)
         near_packet |= (v0.x <= u_hi[half][0]) & (u_lo[half][0] <= v1.x) & (v0.y <= u_hi[half][1]) & (u_lo[half][1] <= v1.y) &
                        (v0.z <= u_hi[half][2]) & (u_lo[half][2] <= v1.z);
       if (TKNN_DIAG_BUILD && (a.diag & 1024) && a.uni) {
@@ -916,9 +984,32 @@ __global__ void __launch_bounds__(kDbUnionBlock) __attribute__((amdgpu_waves_per
       DB_LAP(3);
     }
     if (__ballot(waiting > 0) != 0ull) settle();
+    if (timing && lane == 0) {  // the longest packet, and how many take more than twice / four times 2^20 ticks
+      const unsigned long long el = __builtin_amdgcn_s_memtime() - packet_t0;
+      atomicMax(&a.diag_out[12], el);
+      if (el > (1ull << 20)) atomicAdd(&a.diag_out[10], 1ull);
+      if (el > (1ull << 21)) atomicAdd(&a.diag_out[11], 1ull);
+    }
+    if (timing) {
+      uint32_t lw = pk_long, pt = point_tests - pk_points0;
+      for (int off = 32; off > 0; off >>= 1) lw += __shfl_xor(lw, off), pt += __shfl_xor(pt, off);
+      const unsigned long long el = __builtin_amdgcn_s_memtime() - packet_t0;
+      if (lane == 0 && el > (1ull << 21)) {
+        atomicAdd(&a.diag_out[16], tm[5] - pk_rounds0), atomicAdd(&a.diag_out[17], tm[6] - pk_settles0);
+        atomicAdd(&a.diag_out[18], (unsigned long long)lw), atomicAdd(&a.diag_out[19], (unsigned long long)pt);
+        atomicAdd(&a.diag_out[9], tm[2] - pk_settle_t0);
+        float ext = 0.f;
+        for (int c = 0; c < 3; c++) ext = fmaxf(ext, fmaxf(u_hi[0][c], u_hi[kDbBoxes - 1][c]) - fminf(u_lo[0][c], u_lo[kDbBoxes - 1][c]));
+        printf("[heavy packet] %lld of %lld: %llu ticks, extent %.4f (reach %.4f), first slot %d, pk_root %d, rounds %llu settles %llu\n", packet, packets, el, ext, r, a_first, pk_root,
+               tm[5] - pk_rounds0, tm[6] - pk_settles0);
+      }
+    }
   }
-  if (timing && lane == 0)
+  if (timing && lane == 0) {
     for (int i = 0; i < 8; i++) atomicAdd(&a.diag_out[i], tm[i]);
+    const unsigned long long el = __builtin_amdgcn_s_memtime() - wave_t0;  // how evenly the packets fill the waves: mean / longest wave
+    atomicAdd(&a.diag_out[13], el), atomicMax(&a.diag_out[14], el), atomicAdd(&a.diag_out[15], 1ull);
+  }
 #undef DB_LAP
   if (a.diag & 8) {  // [6] most walk steps of a wave, [7] their sum
     if (lane == 0) {
@@ -926,7 +1017,7 @@ __global__ void __launch_bounds__(kDbUnionBlock) __attribute__((amdgpu_waves_per
       atomicAdd(&a.stats[7], (unsigned long long)node_tests);
     }
   }
-  db_add_stats(a.stats + 2, blk_stats, node_tests, point_tests);
+  db_add_stats_wave(a.stats + 2, node_tests, point_tests);  // (no LDS words: 16 384 bytes per workgroup are ten workgroups per CU, 16 400 are nine)
 }
 
 // min_row[root] = min(min_row[root], row).  The value only falls, so a read that finds it at or below `row` settles the matter
@@ -1178,6 +1269,11 @@ int64_t Engine::dbscan_noise(float eps, int min_pts, uint8_t *d_noise, hipStream
   const int64_t n = bvh_.size();
   size_t scan_bytes = 0;
   OWLMI_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, (int32_t *)nullptr, (int32_t *)nullptr, (int)n, s));
+  {
+    size_t flag_scan_bytes = 0;
+    OWLMI_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, flag_scan_bytes, DbFlagIter(nullptr, DbFlagOf()), (int32_t *)nullptr, (int)n, s));
+    scan_bytes = std::max(scan_bytes, flag_scan_bytes);
+  }
   const size_t need = (((size_t)n * (4 + 4 + 4 + 4 + 1 + 1)) + 32 + 255) / 256 * 256;  // as dbscan_auto
   if (need + scan_bytes > wave_ws_bytes_) {
     if (wave_ws_) (void)hipFree(wave_ws_);
@@ -1208,10 +1304,8 @@ int64_t Engine::dbscan_noise(float eps, int min_pts, uint8_t *d_noise, hipStream
   OWLMI_HIP(hipMemsetAsync(counters_, 0, (kCounters + kDbStripes * 8) * sizeof(unsigned long long), s));
   hipLaunchKernelGGL(db_core_kernel, dim3(blocks), dim3(kDbBlock), 0, s, a);
   {
-    int32_t *flag = a.rank, *pos = a.rank;
-    hipLaunchKernelGGL(db_core_flag_kernel, dim3(blocks), dim3(kDbBlock), 0, s, a, flag);
-    OWLMI_HIP(hipcub::DeviceScan::ExclusiveSum(scan_tmp, scan_bytes, flag, core_rank, (int)n, s));
-    OWLMI_HIP(hipMemsetAsync(pos, 0x7f, ((size_t)n + 1) * sizeof(int32_t), s));
+    int32_t *pos = a.rank;
+    OWLMI_HIP(hipcub::DeviceScan::ExclusiveSum(scan_tmp, scan_bytes, DbFlagIter(a.core_sorted, DbFlagOf()), core_rank, (int)n, s));
     hipLaunchKernelGGL(db_core_pos_kernel, dim3(blocks), dim3(kDbBlock), 0, s, a, core_rank, pos, (int32_t *)nullptr, (unsigned long long *)nullptr);
     hipLaunchKernelGGL(db_next_core_kernel, dim3(blocks1), dim3(kDbBlock), 0, s, a, core_rank, pos, next_core);
   }
@@ -1230,6 +1324,11 @@ void Engine::dbscan(float eps, int min_pts, int32_t *d_labels, uint8_t *d_core, 
   const size_t need = (min_row_at + (size_t)n * 12 + 255) / 256 * 256;  // ... the list of the slots that are not core, their core neighbours
   size_t scan_bytes = 0, select_bytes = 0;
   OWLMI_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, (int32_t *)nullptr, (int32_t *)nullptr, (int)n, s));
+  {
+    size_t flag_scan_bytes = 0;
+    OWLMI_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, flag_scan_bytes, DbFlagIter(nullptr, DbFlagOf()), (int32_t *)nullptr, (int)n, s));
+    scan_bytes = std::max(scan_bytes, flag_scan_bytes);
+  }
   OWLMI_HIP(hipcub::DeviceSelect::If(nullptr, select_bytes, (int32_t *)nullptr, (int32_t *)nullptr, (unsigned long long *)nullptr, (int)n, DbIsGroup(), s));
   scan_bytes = std::max(scan_bytes, select_bytes);
   if (need + scan_bytes > wave_ws_bytes_) {
@@ -1294,11 +1393,9 @@ void Engine::dbscan(float eps, int min_pts, int32_t *d_labels, uint8_t *d_core, 
   {
     // next_core: flags -> exclusive sum (rank of a slot among the core slots) -> slot of the r-th core
     // point -> first core slot at or after each slot.  is_root / rank are free until the unions are done.
-    int32_t *flag = a.rank, *core_rank = is_root, *pos = a.rank;
+    int32_t *core_rank = is_root, *pos = a.rank;
     const unsigned blocks1 = (unsigned)((n + 1 + kDbBlock - 1) / kDbBlock);
-    hipLaunchKernelGGL(db_core_flag_kernel, dim3(blocks), dim3(kDbBlock), 0, s, a, flag);
-    OWLMI_HIP(hipcub::DeviceScan::ExclusiveSum(scan_tmp, scan_bytes, flag, core_rank, (int)n, s));
-    OWLMI_HIP(hipMemsetAsync(pos, 0x7f, ((size_t)n + 1) * sizeof(int32_t), s));  // 0x7f7f7f7f: "none", clamped below
+    OWLMI_HIP(hipcub::DeviceScan::ExclusiveSum(scan_tmp, scan_bytes, DbFlagIter(a.core_sorted, DbFlagOf()), core_rank, (int)n, s));
     hipLaunchKernelGGL(db_core_pos_kernel, dim3(blocks), dim3(kDbBlock), 0, s, a, core_rank, pos, core_label ? (int32_t *)nullptr : not_core, counters_ + 19);
     hipLaunchKernelGGL(db_next_core_kernel, dim3(blocks1), dim3(kDbBlock), 0, s, a, core_rank, pos, next_core);
   }
@@ -1338,6 +1435,7 @@ void Engine::dbscan(float eps, int min_pts, int32_t *d_labels, uint8_t *d_core, 
     unsigned long long *n_groups = counters_ + 8;
     OWLMI_HIP(hipMemsetAsync(n_groups, 0, 10 * sizeof(unsigned long long), s));  // ... and the count of stack overflows in [17]
     a.chunk = getenv("TKNN_DB_CHUNK") ? std::max(1, atoi(getenv("TKNN_DB_CHUNK"))) : 64;
+    a.short_way = getenv("TKNN_DB_SHORT") ? atoi(getenv("TKNN_DB_SHORT")) : 1;
     a.scan_budget = getenv("TKNN_DB_SCAN") ? std::max(0, atoi(getenv("TKNN_DB_SCAN"))) : 12;
     hipLaunchKernelGGL(db_group_kernel, dim3(blocks), dim3(kDbBlock), 0, s, a, group_at);
     OWLMI_HIP(hipcub::DeviceSelect::If(scan_tmp, scan_bytes, group_at, groups, n_groups, (int)n, DbIsGroup(), s));
@@ -1439,8 +1537,13 @@ void Engine::dbscan(float eps, int min_pts, int32_t *d_labels, uint8_t *d_core, 
     info->union_node_tests = (int64_t)h_counters_[2];
     info->groups = per_point ? 0 : (int64_t)h_counters_[8];
     if (a.diag & 512) {
-      unsigned long long t[8];
+      unsigned long long t[20];
       OWLMI_HIP(hipMemcpy(t, counters_ + 20, sizeof t, hipMemcpyDeviceToHost));
+      std::fprintf(stderr, "[dbscan] union kernel: %llu waves, mean time in the kernel %.0f ticks, longest %llu ticks (%.0f %% of it filled on average), in packets %.0f ticks\n", t[15],
+                   (double)t[13] / (double)t[15], t[14], 100.0 * (double)t[13] / (double)t[15] / (double)t[14], (double)(t[0] + t[1] + t[2] + t[3] + t[4]) / (double)t[15]);
+      if (!(a.diag & 1024)) std::fprintf(stderr, "[dbscan] union kernel: longest packet %llu ticks; %llu packets above 2^20 ticks, %llu above 2^21\n", t[12], t[10], t[11]);
+      if (!(a.diag & 1024) && t[11]) std::fprintf(stderr, "[dbscan] union kernel: the packets above 2^21 ticks, each on average: %.1f rounds, %.1f settles (%.0f ticks in them), %.1f entries the long way, %.1f point tests\n",
+                   (double)t[16] / t[11], (double)t[17] / t[11], (double)t[9] / t[11], (double)t[18] / t[11], (double)t[19] / t[11]);
       const double tot = (double)(t[0] + t[1] + t[2] + t[3] + t[4]);
       std::fprintf(stderr, "[dbscan] union kernel wave time: loads %.1f%%  tests %.1f%%  settles %.1f%%  pushes %.1f%%  packet set-up %.1f%%;  %.1f rounds and %.1f settles per packet, %llu packet walks, %.1f us per packet walk (s_memtime at 100 MHz)\n",
                    100 * t[0] / tot, 100 * t[1] / tot, 100 * t[2] / tot, 100 * t[3] / tot, 100 * t[4] / tot, (double)t[5] / (double)t[7], (double)t[6] / (double)t[7], t[7], tot / 100.0 / (double)t[7]);
@@ -1470,6 +1573,11 @@ void Engine::dbscan_auto(float eps0, int min_pts, double max_noise, int max_roun
   // core flags per slot, noise flags per slot
   size_t scan_bytes = 0;
   OWLMI_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, (int32_t *)nullptr, (int32_t *)nullptr, (int)n, s));
+  {
+    size_t flag_scan_bytes = 0;
+    OWLMI_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, flag_scan_bytes, DbFlagIter(nullptr, DbFlagOf()), (int32_t *)nullptr, (int)n, s));
+    scan_bytes = std::max(scan_bytes, flag_scan_bytes);
+  }
   const size_t need = (((size_t)n * (4 + 4 + 4 + 4 + 1 + 1)) + 32 + 255) / 256 * 256;
   if (need + scan_bytes > wave_ws_bytes_) {
     if (wave_ws_) (void)hipFree(wave_ws_);
@@ -1508,10 +1616,8 @@ void Engine::dbscan_auto(float eps0, int min_pts, double max_noise, int max_roun
     OWLMI_HIP(hipMemsetAsync(counters_, 0, (kCounters + kDbStripes * 8) * sizeof(unsigned long long), s));
     hipLaunchKernelGGL(db_core_kernel, dim3(blocks), dim3(kDbBlock), 0, s, a);
     {
-      int32_t *flag = a.rank, *pos = a.rank;
-      hipLaunchKernelGGL(db_core_flag_kernel, dim3(blocks), dim3(kDbBlock), 0, s, a, flag);
-      OWLMI_HIP(hipcub::DeviceScan::ExclusiveSum(scan_tmp, scan_bytes, flag, core_rank, (int)n, s));
-      OWLMI_HIP(hipMemsetAsync(pos, 0x7f, ((size_t)n + 1) * sizeof(int32_t), s));
+      int32_t *pos = a.rank;
+        OWLMI_HIP(hipcub::DeviceScan::ExclusiveSum(scan_tmp, scan_bytes, DbFlagIter(a.core_sorted, DbFlagOf()), core_rank, (int)n, s));
       hipLaunchKernelGGL(db_core_pos_kernel, dim3(blocks), dim3(kDbBlock), 0, s, a, core_rank, pos, (int32_t *)nullptr, (unsigned long long *)nullptr);
       hipLaunchKernelGGL(db_next_core_kernel, dim3(blocks1), dim3(kDbBlock), 0, s, a, core_rank, pos, next_core);
     }

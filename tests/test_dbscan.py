@@ -140,6 +140,45 @@ def test_group_unions_equal_point_unions(monkeypatch):
     eng.close()
 
 
+@pytest.mark.gpu
+def test_one_set_shortcut_and_side_stream_walks_change_nothing(monkeypatch):
+    """Round 3: the second union pass drops tree nodes whose core points were ONE set when the first pass ended
+    (db_uniform_kernel; TKNN_DB_UNIFORM=0: off), and the points that are not core walk for their core neighbours on a side
+    stream beside the unions, leaving lists the label kernel reads (TKNN_DB_SIDE=0: the label kernel walks).  Labels, core
+    flags and cluster counts must be the spec's either way -- on a mixture (clusters of one set, borders), on a set that is
+    mostly noise (the lists do not fit their room: the label kernel walks by itself), with a minPts so large that a few
+    listed points already overflow the room, and on slabs whose halves join only in the second pass."""
+    from owlraytracing_amd.trueknn import TrueKNN
+    rng = np.random.default_rng(21)
+    slab = lambda m: rng.uniform(0, 1, (m, 3)).astype(np.float32) * np.float32([0.2, 0.2, 0.02])
+    sparse = datasets.uniform3d(60_000, seed=22)
+    sparse[:6000] = np.float32(0.5) + np.float32(0.01) * rng.standard_normal((6000, 3)).astype(np.float32)
+    cases = [
+        ("gmm", datasets.gaussian_mixture3d(200_000, components=16, sigma=0.02, seed=3), 0.01, 4),
+        ("mostly_noise", sparse, 0.004, 4),
+        ("large_min_pts", datasets.gaussian_mixture3d(60_000, components=8, sigma=0.03, seed=4), 0.02, 40),
+        ("slabs_joined_late", np.concatenate([slab(40000), slab(40000) + np.float32([0, 0, 0.0271])]), 0.0104, 4),
+    ]
+    eng = TrueKNN()
+    for name, xyz, eps, min_pts in cases:
+        eps = float(np.float32(eps))
+        ref = oracle.dbscan(xyz, eps, min_pts)
+        eng.build(xyz)
+        for env in ({}, {"TKNN_DB_UNIFORM": "0"}, {"TKNN_DB_SIDE": "0"}, {"TKNN_DB_UNIFORM": "0", "TKNN_DB_SIDE": "0"}):
+            for k in ("TKNN_DB_UNIFORM", "TKNN_DB_SIDE"):
+                monkeypatch.delenv(k, raising=False)
+            for k, v in env.items():
+                monkeypatch.setenv(k, v)
+            for _ in range(2):  # (twice: the second call meets the side stream and the workspace of the first)
+                got = eng.dbscan(eps, min_pts)
+                assert got["info"]["clusters"] == ref["clusters"], (name, env)
+                assert np.array_equal(got["labels"].cpu().numpy(), ref["labels"]), (name, env)
+                assert np.array_equal(got["core"].cpu().numpy().astype(bool), ref["core"].astype(bool)), (name, env)
+        for k in ("TKNN_DB_UNIFORM", "TKNN_DB_SIDE"):
+            monkeypatch.delenv(k, raising=False)
+    eng.close()
+
+
 def _gap_quadruples(eps, split=0.25, rel=(-1e-5, 1e-5), steps=81):
     """Pairs of two-point groups facing each other along ONE axis across a gap of split * eps * (1 + d), d swept over
     `rel` -- the seam between the two passes of the group-union kernel (first pass: nearest faces within split * eps,
