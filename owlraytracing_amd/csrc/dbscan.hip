@@ -488,15 +488,20 @@ struct DbIsGroup {
 // per slot: the group's reference (node, or ~slot of a single point) at the group's first slot if the group has a core
 // point, LBVH_END everywhere else -- compacted into the list, in slot order, by a select.  The core-flag kernel has left
 // every point's group in group_of (it walks the point's root path anyway).
-__global__ void __launch_bounds__(kDbBlock) db_group_kernel(DbArgs a, int32_t *group_at) {
+// (The kernel also fills, as it streams by, what later launches want filled: a fill is a launch of its own otherwise.)
+__global__ void __launch_bounds__(kDbBlock) db_group_kernel(DbArgs a, int32_t *group_at, int32_t *fill_uni, int32_t *fill_min_row) {
   const LbvhView &bvh = a.bvh;
   const int32_t t = blockIdx.x * kDbBlock + threadIdx.x;
   if (t >= bvh.n) return;
+  fill_uni[t] = -1;                 // db_uniform_kernel: nobody has arrived
+  fill_min_row[t] = 0x7f7f7f7f;     // db_flatten_kernel: above every row
   const int32_t g = a.group_of[t];
   const bool leads = g >= 0 || g == ~t;
   const int32_t first = leads ? t : ~g;
   const int32_t s = a.next_core[first];
-  if (a.core_sorted[t] && s != t && !(a.diag & 4)) uf_unite(a.parent, t, s);  // s < t: both core, one group
+  // s < t, both core, one group: united by a plain store -- these are the call's first unions, every slot is still its own
+  // root, s stays one throughout this kernel (only later slots are hooked, under it), and parent[t] is written by nobody else
+  if (a.core_sorted[t] && s != t && !(a.diag & 4)) a.parent[t] = s;
   int32_t out = LBVH_END;
   if (leads) {
     const int32_t last = g >= 0 ? lbvh_last(g, bvh.nodes[g].other) : t;
@@ -1000,8 +1005,7 @@ __global__ void __launch_bounds__(kDbUnionBlock) __attribute__((amdgpu_waves_per
         atomicAdd(&a.diag_out[9], tm[2] - pk_settle_t0);
         float ext = 0.f;
         for (int c = 0; c < 3; c++) ext = fmaxf(ext, fmaxf(u_hi[0][c], u_hi[kDbBoxes - 1][c]) - fminf(u_lo[0][c], u_lo[kDbBoxes - 1][c]));
-        printf("[heavy packet] %lld of %lld: %llu ticks, extent %.4f (reach %.4f), first slot %d, pk_root %d, rounds %llu settles %llu\n", packet, packets, el, ext, r, a_first, pk_root,
-               tm[5] - pk_rounds0, tm[6] - pk_settles0);
+(void)ext;
       }
     }
   }
@@ -1030,8 +1034,9 @@ __device__ __forceinline__ void db_min_row(int32_t *cell, int32_t row) {
 // after the unions: every core slot points at its root, and the root learns the smallest ROW of its cluster -- clusters are
 // numbered by that (the spec: ascending smallest core index).  A wave's slots mostly share one root: one atomic per wave
 // and root, not per point.
-__global__ void __launch_bounds__(kDbBlock) db_flatten_kernel(DbArgs a) {
+__global__ void __launch_bounds__(kDbBlock) db_flatten_kernel(DbArgs a, int32_t *zero) {
   const int32_t t = blockIdx.x * kDbBlock + threadIdx.x;
+  if (t < a.bvh.n) zero[t] = 0;  // the root flags of the next launch (the group list lived here)
   const bool core = t < a.bvh.n && a.core_sorted[t];
   int32_t root = -1, row = 0x7fffffff;
   if (core) {
@@ -1321,7 +1326,7 @@ void Engine::dbscan(float eps, int min_pts, int32_t *d_labels, uint8_t *d_core, 
   const int64_t n = bvh_.size();
   // scratch: core flags per slot, parent, root flags, ranks, next_core (+ two sentinels), smallest rows
   const size_t min_row_at = ((size_t)n * 17 + 8 + 15) / 16 * 16;
-  const size_t need = (min_row_at + (size_t)n * 12 + 255) / 256 * 256;  // ... the list of the slots that are not core, their core neighbours
+  const size_t need = (min_row_at + (size_t)n * 16 + 255) / 256 * 256;  // ... the list of the slots that are not core, their core neighbours
   size_t scan_bytes = 0, select_bytes = 0;
   OWLMI_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, (int32_t *)nullptr, (int32_t *)nullptr, (int)n, s));
   {
@@ -1354,6 +1359,7 @@ void Engine::dbscan(float eps, int min_pts, int32_t *d_labels, uint8_t *d_core, 
   a.core_sorted = (uint8_t *)(ws + (size_t)n * 16 + 8);
   a.min_row = (int32_t *)(ws + min_row_at);
   int32_t *not_core = a.min_row + n;  // in slot order; its length in counters_[19]
+  int32_t *uni = not_core + 2 * (size_t)n;  // db_uniform_kernel's per-node sets (behind border_lists)
   int32_t *border_lists = not_core + n;  // `border_per` words per listed point, if they fit n words: a count and the core neighbours
   const int border_per = std::max(2, min_pts);
   const bool side = !core_label && !(getenv("TKNN_DB_SIDE") && atoi(getenv("TKNN_DB_SIDE")) == 0);  // (0: measurements without the side stream)
@@ -1433,11 +1439,11 @@ void Engine::dbscan(float eps, int min_pts, int32_t *d_labels, uint8_t *d_core, 
     // the list are neighbours in space) where the root flags go; its length in counters_[8], the XCDs' cursors in [9..16]
     int32_t *group_at = a.rank, *groups = is_root;
     unsigned long long *n_groups = counters_ + 8;
-    OWLMI_HIP(hipMemsetAsync(n_groups, 0, 10 * sizeof(unsigned long long), s));  // ... and the count of stack overflows in [17]
+    // (... and the count of stack overflows in [17]; all zero since the call's first memset)
     a.chunk = getenv("TKNN_DB_CHUNK") ? std::max(1, atoi(getenv("TKNN_DB_CHUNK"))) : 64;
     a.short_way = getenv("TKNN_DB_SHORT") ? atoi(getenv("TKNN_DB_SHORT")) : 1;
     a.scan_budget = getenv("TKNN_DB_SCAN") ? std::max(0, atoi(getenv("TKNN_DB_SCAN"))) : 12;
-    hipLaunchKernelGGL(db_group_kernel, dim3(blocks), dim3(kDbBlock), 0, s, a, group_at);
+    hipLaunchKernelGGL(db_group_kernel, dim3(blocks), dim3(kDbBlock), 0, s, a, group_at, uni, a.min_row);
     OWLMI_HIP(hipcub::DeviceSelect::If(scan_tmp, scan_bytes, group_at, groups, n_groups, (int)n, DbIsGroup(), s));
     // persistent lanes: as many workgroups as the device holds at once (the list's length is known on the device only)
     // (per engine: the CU count and the occupancy are those of THIS engine's device)
@@ -1448,7 +1454,10 @@ void Engine::dbscan(float eps, int min_pts, int32_t *d_labels, uint8_t *d_core, 
         db_union_resident_ = 256 * 4;
       } else {
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)db_group_union_kernel, kDbUnionBlock, 0) != hipSuccess) per_cu = 4;
-        db_union_resident_ = prop.multiProcessorCount * std::max(1, per_cu);
+        // nine workgroups = 18 waves per CU, one fewer than fit: the launch lasts as long as its slowest packets (sparse
+        // outskirts: three times the average walk), and those run faster with fewer waves on their SIMD -- BASELINE config 3,
+        // both passes: 1.83 ms with ten, 1.74 with nine, 1.77 with eight, 1.82 with seven
+        db_union_resident_ = prop.multiProcessorCount * std::max(1, std::min(per_cu, 9));
       }
     }
     const int resident = db_union_resident_;
@@ -1474,10 +1483,9 @@ void Engine::dbscan(float eps, int min_pts, int32_t *d_labels, uint8_t *d_core, 
       a.near_lo2 = a.near_hi2;
       if (n > 1 && !(getenv("TKNN_DB_UNIFORM") && atoi(getenv("TKNN_DB_UNIFORM")) == 0)) {  // (0: measurements without it)
         // which nodes hold one set only, now that the groups that touch are united (min_row's place is free until the unions are done)
-        a.uni = a.min_row;
+        a.uni = uni;          // (filled by db_group_kernel)
         a.uni_leaf = a.rank;  // (the select has used the per-slot group references up)
         a.split_owner = bvh_.split_owner_device();
-        OWLMI_HIP(hipMemsetAsync(a.uni, 0xff, (size_t)n * sizeof(int32_t), s));
         hipLaunchKernelGGL(db_uniform_kernel, dim3(blocks), dim3(kDbBlock), 0, s, a, groups, n_groups);
       }
     }
@@ -1486,9 +1494,8 @@ void Engine::dbscan(float eps, int min_pts, int32_t *d_labels, uint8_t *d_core, 
     hipLaunchKernelGGL(db_group_union_kernel, dim3(grid), dim3(kDbUnionBlock), 0, s, a, groups, n_groups, n_groups + 1, n_groups + 9);
   }
   OWLMI_HIP(hipEventRecord(ev_e_, s));
-  OWLMI_HIP(hipMemsetAsync(a.min_row, 0x7f, (size_t)n * sizeof(int32_t), s));  // 0x7f7f7f7f: above every row
-  hipLaunchKernelGGL(db_flatten_kernel, dim3(blocks), dim3(kDbBlock), 0, s, a);
-  OWLMI_HIP(hipMemsetAsync(is_root, 0, (size_t)n * sizeof(int32_t), s));  // (the group list lived here)
+  if (per_point) OWLMI_HIP(hipMemsetAsync(a.min_row, 0x7f, (size_t)n * sizeof(int32_t), s));  // 0x7f7f7f7f: above every row (else: db_group_kernel)
+  hipLaunchKernelGGL(db_flatten_kernel, dim3(blocks), dim3(kDbBlock), 0, s, a, is_root);
   hipLaunchKernelGGL(db_root_kernel, dim3(blocks), dim3(kDbBlock), 0, s, a, is_root);
   OWLMI_HIP(hipGetLastError());
   OWLMI_HIP(hipcub::DeviceScan::ExclusiveSum(scan_tmp, scan_bytes, is_root, a.rank, (int)n, s));
