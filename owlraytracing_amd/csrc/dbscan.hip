@@ -66,6 +66,7 @@ struct DbArgs {
   float reach, near_lo2, near_hi2;  // this pass of db_group_union_kernel: groups whose nearest faces are near_lo2 < d^2 <= near_hi2 apart, reach >= sqrt(near_hi2)
   // second pass of db_group_union_kernel: uni[node] >= 0: every core point under the node is in the set that slot was the root
   // of when the first pass had ended (db_uniform_kernel); negative: not known to be one set
+  const int32_t *block_paths;  // Lbvh::block_paths_device(), or null: where a slot's walk down to its group may start
   const int32_t *split_owner;  // Lbvh::split_owner_device()
   int32_t *uni;       // per internal node
   int32_t *uni_leaf;  // per sorted slot, written for the listed groups that are single points only
@@ -249,11 +250,31 @@ __device__ __forceinline__ void db_core_body(const DbArgs &a, int32_t t, uint32_
   // decide looks for its minPts neighbours there FIRST: they are next to it, a walk from the root spends two dozen steps
   // getting near (BASELINE config 3: a fifth of the points walk, nearly all of them core, 0.9 of the pass's 1.4 ms).
   constexpr int kNear = 4;
+  static_assert(kNear == LBVH_PATH_WORDS - 1, "the block paths hold the ring's ancestors");
   int32_t anc[kNear];
 #pragma unroll
   for (int j = 0; j < kNear; j++) anc[j] = bvh.root;
   if (!a.want_counts || a.group_of) {
     int32_t node = bvh.root, first = t;
+    if (a.block_paths) {
+      // Not from the root: from the deepest node that holds the wave's 64 slots (a table of the tree, LBVH_PATH_BLOCK), with
+      // that node's four nearest ancestors in the ring -- if it is not tight none of its ancestors is (a parent's box holds
+      // the child's), and the walk from the root would have come through here with exactly this ring (config 3: 16 of a
+      // point's 23 steps).  If it is tight, the group is that node or one of the ancestors: the highest tight one among the
+      // four the table has -- unless the fourth is tight too, then the walk starts at the root after all.
+      const int32_t *bp = a.block_paths + (size_t)(t / LBVH_PATH_BLOCK) * LBVH_PATH_WORDS;
+      const int32_t a4 = bp[0], a3 = bp[1], a2 = bp[2], a1 = bp[3], lca = bp[4];
+      if (!node_is_tight(bvh.nodes[lca], a.eps_in2)) {
+        node = lca;
+        anc[0] = a4, anc[1] = a3, anc[2] = a2, anc[3] = a1;
+      } else {
+        const bool t1 = node_is_tight(bvh.nodes[a1], a.eps_in2), t2 = node_is_tight(bvh.nodes[a2], a.eps_in2),
+                   t3 = node_is_tight(bvh.nodes[a3], a.eps_in2), t4 = node_is_tight(bvh.nodes[a4], a.eps_in2);
+        node_tests += 4;
+        if (!t4) node = t3 ? a3 : t2 ? a2 : t1 ? a1 : lca;  // (the ring stays at the root: no subtree to count in first)
+      }
+      node_tests++;
+    }
     if (TKNN_DIAG_BUILD && (a.diag & 128)) node = -1;  // (times only) no descent to the group
     while (node >= 0) {
       const LbvhNode nd = bvh.nodes[node];
@@ -1290,6 +1311,7 @@ int64_t Engine::dbscan_noise(float eps, int min_pts, uint8_t *d_noise, hipStream
   DbArgs a;
   std::memset(&a, 0, sizeof a);
   a.bvh = bvh_.view();
+  a.block_paths = (getenv("TKNN_DB_PATHS") && atoi(getenv("TKNN_DB_PATHS")) == 0) ? nullptr : bvh_.block_paths_device();  // (0: measurements)
   a.min_pts = min_pts;
   a.eps = eps;
   a.eps_wide = eps * 1.000001f;
@@ -1346,6 +1368,7 @@ void Engine::dbscan(float eps, int min_pts, int32_t *d_labels, uint8_t *d_core, 
   DbArgs a;
   std::memset(&a, 0, sizeof a);
   a.bvh = bvh_.view();
+  a.block_paths = (getenv("TKNN_DB_PATHS") && atoi(getenv("TKNN_DB_PATHS")) == 0) ? nullptr : bvh_.block_paths_device();  // (0: measurements)
   a.eps = eps;
   a.eps_wide = eps * 1.000001f;
   a.min_pts = min_pts;
@@ -1596,6 +1619,7 @@ void Engine::dbscan_auto(float eps0, int min_pts, double max_noise, int max_roun
   DbArgs a;
   std::memset(&a, 0, sizeof a);
   a.bvh = bvh_.view();
+  a.block_paths = (getenv("TKNN_DB_PATHS") && atoi(getenv("TKNN_DB_PATHS")) == 0) ? nullptr : bvh_.block_paths_device();  // (0: measurements)
   a.min_pts = min_pts;
   a.keep_core = 1;
   a.parent = nullptr;           // no unions in the growth rounds: the slots' place holds ...

@@ -9,6 +9,9 @@
 
 #include "owl/lbvh_device.h"
 
+#define LBVH_PATH_BLOCK 64
+#define LBVH_PATH_WORDS 5
+
 namespace owlmi {
 
 struct HipError {
@@ -54,6 +57,10 @@ class Lbvh {
   // -- internal node i is a left child iff it is its range's LAST position (parent = split_owner[i]), else a right child
   // (parent = split_owner[i - 1]); valid as long as the tree is
   const int32_t *split_owner_device() const { return split_owner_; }
+  // point trees: per block of LBVH_PATH_BLOCK consecutive sorted slots, LBVH_PATH_WORDS nodes -- the deepest internal node whose
+  // range holds the whole block (last word) and its four nearest ancestors, the farthest first (the root where the path is
+  // shorter): a walk down to one of the block's slots can start there instead of at the root
+  const int32_t *block_paths_device() const { return point_mode_ && n_ > 1 ? block_paths_ : nullptr; }
   int64_t size() const { return n_; }
   bool built() const { return built_; }
   void clear() { built_ = false; }  // marks the tree unusable (a failed rebuild); memory stays reserved
@@ -80,7 +87,7 @@ class Lbvh {
   void *sort_tmp_ = nullptr;
   size_t sort_tmp_bytes_ = 0;
   LbvhNode *nodes_ = nullptr;
-  int32_t *split_owner_ = nullptr, *rope_node_ = nullptr, *rope_leaf_ = nullptr;
+  int32_t *split_owner_ = nullptr, *rope_node_ = nullptr, *rope_leaf_ = nullptr, *block_paths_ = nullptr;
   LbvhPoint *points_ = nullptr;
   LbvhBox *boxes_ = nullptr;  // sorted boxes (box mode)
   int32_t *prim_id_ = nullptr;

@@ -273,6 +273,33 @@ __global__ void __launch_bounds__(kBlock) block_box_kernel(const LbvhPoint *__re
   out[b] = o;
 }
 
+// Lbvh::block_paths_device(): one thread per block of LBVH_PATH_BLOCK sorted slots walks from the root to the deepest
+// internal node that still holds the whole block, keeping the last four nodes it came through
+__global__ void __launch_bounds__(kBlock) block_path_kernel(const LbvhNode *__restrict__ nodes, int64_t n, int32_t *__restrict__ paths,
+                                                           int64_t n_blocks) {
+  const int64_t b = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (b >= n_blocks) return;
+  const int32_t lo = (int32_t)(b * LBVH_PATH_BLOCK), hi = (int32_t)((b + 1) * LBVH_PATH_BLOCK - 1 < n - 1 ? (b + 1) * LBVH_PATH_BLOCK - 1 : n - 1);
+  int32_t anc[4] = {0, 0, 0, 0}, node = 0;
+  for (;;) {
+    const LbvhNode nd = nodes[node];
+    int32_t next;
+    if (hi <= nd.split) {
+      if (lbvh_first(node, nd.other) == nd.split) break;  // the child is a leaf (a block of one slot)
+      next = nd.split;
+    } else if (lo > nd.split) {
+      if (lbvh_last(node, nd.other) == nd.split + 1) break;
+      next = nd.split + 1;
+    } else {
+      break;  // the block lies on both sides
+    }
+    anc[0] = anc[1], anc[1] = anc[2], anc[2] = anc[3], anc[3] = node;
+    node = next;
+  }
+  int32_t *out = paths + b * LBVH_PATH_WORDS;
+  out[0] = anc[0], out[1] = anc[1], out[2] = anc[2], out[3] = anc[3], out[4] = node;
+}
+
 struct Pyramid {
   const LbvhPoint *points;
   const LbvhBox *boxes;
@@ -351,7 +378,7 @@ void Lbvh::release() {
     w = nullptr;
   }
   void *ptrs[] = {scene_, partials_, codes_, codes_alt_, order_, order_alt_, sort_tmp_, nodes_,
-                  split_owner_, rope_node_, rope_leaf_, points_, boxes_, prim_id_, table_[0],
+                  split_owner_, rope_node_, rope_leaf_, block_paths_, points_, boxes_, prim_id_, table_[0],
                   table_[1], table_[2], table_[3]};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
@@ -360,7 +387,7 @@ void Lbvh::release() {
   order_ = order_alt_ = nullptr;
   sort_tmp_ = nullptr;
   nodes_ = nullptr;
-  split_owner_ = rope_node_ = rope_leaf_ = nullptr;
+  split_owner_ = rope_node_ = rope_leaf_ = block_paths_ = nullptr;
   points_ = nullptr;
   boxes_ = nullptr;
   prim_id_ = nullptr;
@@ -389,6 +416,7 @@ void Lbvh::reserve(int64_t n) {
   dev_alloc(split_owner_, (size_t)n, total);
   dev_alloc(rope_node_, (size_t)n, total);
   dev_alloc(rope_leaf_, (size_t)n, total);
+  dev_alloc(block_paths_, ((size_t)n / LBVH_PATH_BLOCK + 1) * LBVH_PATH_WORDS, total);
   dev_alloc(points_, (size_t)n + 2 * LBVH_BLOCK, total);  // + NaN sentinels up to a whole leaf block, + one all-NaN block
   dev_alloc(boxes_, (size_t)n, total);
   dev_alloc(prim_id_, (size_t)n, total);
@@ -491,6 +519,11 @@ void Lbvh::build_from_points(const float *d_xyz, int64_t n, hipStream_t stream, 
   OWLMI_HIP(hipGetLastError());
   fit(stream);
   build_wide(stream);
+  if (n > 1) {
+    const int64_t n_blocks = (n + LBVH_PATH_BLOCK - 1) / LBVH_PATH_BLOCK;
+    hipLaunchKernelGGL(block_path_kernel, dim3(blocks_for(n_blocks)), dim3(kBlock), 0, stream, nodes_, n, block_paths_, n_blocks);
+    OWLMI_HIP(hipGetLastError());
+  }
   built_ = true;
 }
 

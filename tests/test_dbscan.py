@@ -144,7 +144,8 @@ def test_group_unions_equal_point_unions(monkeypatch):
 def test_one_set_shortcut_and_side_stream_walks_change_nothing(monkeypatch):
     """Round 3: the second union pass drops tree nodes whose core points were ONE set when the first pass ended
     (db_uniform_kernel; TKNN_DB_UNIFORM=0: off), and the points that are not core walk for their core neighbours on a side
-    stream beside the unions, leaving lists the label kernel reads (TKNN_DB_SIDE=0: the label kernel walks).  Labels, core
+    stream beside the unions, leaving lists the label kernel reads (TKNN_DB_SIDE=0: the label kernel walks); a point's walk
+    down to its group starts at the node over its wave's 64 slots (TKNN_DB_PATHS=0: at the root).  Labels, core
     flags and cluster counts must be the spec's either way -- on a mixture (clusters of one set, borders), on a set that is
     mostly noise (the lists do not fit their room: the label kernel walks by itself), with a minPts so large that a few
     listed points already overflow the room, and on slabs whose halves join only in the second pass."""
@@ -158,14 +159,18 @@ def test_one_set_shortcut_and_side_stream_walks_change_nothing(monkeypatch):
         ("mostly_noise", sparse, 0.004, 4),
         ("large_min_pts", datasets.gaussian_mixture3d(60_000, components=8, sigma=0.03, seed=4), 0.02, 40),
         ("slabs_joined_late", np.concatenate([slab(40000), slab(40000) + np.float32([0, 0, 0.0271])]), 0.0104, 4),
+        # blobs of 150 .. 900 points, each far smaller than eps: the node over a wave's 64 slots is tight, the group is one to
+        # four levels above it (block paths: the walk to the group starts at that node's ancestors, or at the root)
+        ("blobs_within_eps", np.concatenate([c + np.float32(0.0004) * rng.standard_normal((m, 3)).astype(np.float32)
+                                             for c, m in zip(rng.uniform(0, 1, (60, 3)).astype(np.float32), rng.integers(150, 900, 60))]), 0.01, 4),
     ]
     eng = TrueKNN()
     for name, xyz, eps, min_pts in cases:
         eps = float(np.float32(eps))
         ref = oracle.dbscan(xyz, eps, min_pts)
         eng.build(xyz)
-        for env in ({}, {"TKNN_DB_UNIFORM": "0"}, {"TKNN_DB_SIDE": "0"}, {"TKNN_DB_UNIFORM": "0", "TKNN_DB_SIDE": "0"}):
-            for k in ("TKNN_DB_UNIFORM", "TKNN_DB_SIDE"):
+        for env in ({}, {"TKNN_DB_UNIFORM": "0"}, {"TKNN_DB_SIDE": "0"}, {"TKNN_DB_UNIFORM": "0", "TKNN_DB_SIDE": "0"}, {"TKNN_DB_PATHS": "0"}):
+            for k in ("TKNN_DB_UNIFORM", "TKNN_DB_SIDE", "TKNN_DB_PATHS"):
                 monkeypatch.delenv(k, raising=False)
             for k, v in env.items():
                 monkeypatch.setenv(k, v)
@@ -174,7 +179,7 @@ def test_one_set_shortcut_and_side_stream_walks_change_nothing(monkeypatch):
                 assert got["info"]["clusters"] == ref["clusters"], (name, env)
                 assert np.array_equal(got["labels"].cpu().numpy(), ref["labels"]), (name, env)
                 assert np.array_equal(got["core"].cpu().numpy().astype(bool), ref["core"].astype(bool)), (name, env)
-        for k in ("TKNN_DB_UNIFORM", "TKNN_DB_SIDE"):
+        for k in ("TKNN_DB_UNIFORM", "TKNN_DB_SIDE", "TKNN_DB_PATHS"):
             monkeypatch.delenv(k, raising=False)
     eng.close()
 
