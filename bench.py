@@ -522,7 +522,9 @@ def dbscan_rooflines(info, infos, n_local, min_pts):
             "launches_per_step": launches,
             "kernel_ms": kern_ms,
             "timing": "HIP events on the launch stream, recorded inside libowl_mi355x.so around the kernel's launches"
-                      + (" (label_ms covers db_label_kernel + db_label_walk_kernel)" if nm == "label_ms" else ""),
+                      + (" (the label kernel's launch; the walks of the points that are not core -- whose point tests these are -- run in "
+                         "db_border_walk_kernel beside the unions, on a stream of their own)" if nm == "label_ms" else "")
+                      + (" (the two launches; db_uniform_kernel between them is not in it)" if nm == "union_ms" else ""),
         }
         rec, why_not = committed_profile(kernel_name, n_local, min_pts)
         if rec:

@@ -278,6 +278,8 @@ Engine::Engine() {
   OWLMI_HIP(hipEventCreate(&ev_d_));
   OWLMI_HIP(hipEventCreate(&ev_e_));
   OWLMI_HIP(hipEventCreate(&ev_f_));
+  OWLMI_HIP(hipEventCreate(&ev_g_));
+  OWLMI_HIP(hipEventCreate(&ev_h_));
   OWLMI_HIP(hipMalloc((void **)&counters_, (kCounters + kDbStripes * 8) * sizeof(unsigned long long)));  // [16..23]: the team kernel's per-XCD packet counters; [32]: tie rows
   OWLMI_HIP(hipMalloc((void **)&tie_list_, kTieListCap * sizeof(int32_t)));
   OWLMI_HIP(hipHostMalloc((void **)&h_counters_, (16 + kDbStripes * 8) * sizeof(unsigned long long)));
@@ -306,6 +308,8 @@ Engine::~Engine() {
   if (ev_d_) (void)hipEventDestroy(ev_d_);
   if (ev_e_) (void)hipEventDestroy(ev_e_);
   if (ev_f_) (void)hipEventDestroy(ev_f_);
+  if (ev_g_) (void)hipEventDestroy(ev_g_);
+  if (ev_h_) (void)hipEventDestroy(ev_h_);
   if (ev_side_a_) (void)hipEventDestroy(ev_side_a_);
   if (ev_side_b_) (void)hipEventDestroy(ev_side_b_);
   if (db_side_) (void)hipStreamDestroy(db_side_);
