@@ -244,6 +244,14 @@ TKNN_API int tknnDbscanNoise(tknnEngine e, float eps, int min_pts, uint8_t *d_no
 TKNN_API int tknnExportTree(tknnEngine e, void *nodes, int32_t *rope_node, int32_t *rope_leaf,
                             int32_t *prim_id, void *stream);
 
+/* Test hook: the builder's two side tables of a point tree with n > 1 (host buffers).
+ *   split_owner  n-1: the internal node that splits its range after sorted position s -- an internal node i is a left
+ *                child iff i is the LAST position of its range (parent = split_owner[i]), else a right child (parent =
+ *                split_owner[i-1]); RT-DBSCAN climbs with it (owlraytracing_amd/csrc/dbscan.hip, db_uniform_kernel)
+ *   block_paths  ceil(n/64) x 5: per block of 64 sorted slots the deepest internal node whose range holds the whole block
+ *                (last word) and its four nearest ancestors, farthest first, the root where the path is shorter            */
+TKNN_API int tknnExportTreeTables(tknnEngine e, int32_t *split_owner, int32_t *block_paths, void *stream);
+
 /* Test hook for the wave kernel's candidate test.  For each pair (q[i], r[i]) writes lo[i], hi[i]
  * such that, for every fp32 c,   lo <= c <= hi   <=>   fl(c - r) <= q <= fl(c + r)
  * (the box the bounds program of deviceCode.cu:38-56 writes, tested against the query point). */

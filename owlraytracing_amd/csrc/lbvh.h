@@ -70,6 +70,8 @@ class Lbvh {
   // debug / test export (host copies)
   void download(LbvhNode *nodes, int32_t *rope_node, int32_t *rope_leaf, int32_t *prim_id,
                 hipStream_t stream) const;
+  // split_owner: n - 1 entries; block_paths: ceil(n / LBVH_PATH_BLOCK) * LBVH_PATH_WORDS (point trees with n > 1)
+  void download_tables(int32_t *split_owner, int32_t *block_paths, hipStream_t stream) const;
 
  private:
   void reserve(int64_t n);

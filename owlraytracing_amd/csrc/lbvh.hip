@@ -582,4 +582,14 @@ void Lbvh::download(LbvhNode *nodes, int32_t *rope_node, int32_t *rope_leaf, int
   OWLMI_HIP(hipStreamSynchronize(stream));
 }
 
+void Lbvh::download_tables(int32_t *split_owner, int32_t *block_paths, hipStream_t stream) const {
+  if (!built_) throw HipError{"Lbvh::download_tables: not built"};
+  if (split_owner && n_ > 1)
+    OWLMI_HIP(hipMemcpyAsync(split_owner, split_owner_, (size_t)(n_ - 1) * 4, hipMemcpyDeviceToHost, stream));
+  if (block_paths && block_paths_device())
+    OWLMI_HIP(hipMemcpyAsync(block_paths, block_paths_, (size_t)((n_ + LBVH_PATH_BLOCK - 1) / LBVH_PATH_BLOCK) * LBVH_PATH_WORDS * 4,
+                             hipMemcpyDeviceToHost, stream));
+  OWLMI_HIP(hipStreamSynchronize(stream));
+}
+
 }  // namespace owlmi

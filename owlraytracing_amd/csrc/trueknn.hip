@@ -853,6 +853,17 @@ int tknnExportTree(tknnEngine e, void *nodes, int32_t *rope_node, int32_t *rope_
   });
 }
 
+int tknnExportTreeTables(tknnEngine e, int32_t *split_owner, int32_t *block_paths, void *stream) {
+  if (!e) {
+    g_last_error = "tknnExportTreeTables: engine is NULL";
+    return TKNN_E_ARG;
+  }
+  return guarded_on(e, [&] {
+    if (!e->impl.built()) throw owlmi::ArgError{TKNN_E_STATE, "tknnExportTreeTables: call tknnBuild first"};
+    e->impl.tree().download_tables(split_owner, block_paths, (hipStream_t)stream);
+  });
+}
+
 int tknnDebugThresholds(const float *d_q, const float *d_r, int64_t n, float *d_lo, float *d_hi, void *stream) {
   if (!d_q || !d_r || !d_lo || !d_hi || n < 0) {
     g_last_error = "tknnDebugThresholds: null pointer";

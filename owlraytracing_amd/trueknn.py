@@ -251,8 +251,12 @@ class TrueKNN:
         with torch.cuda.device(self.device):
             _lib.check(self._lib.tknnExportTree(self._h, nodes.ctypes.data, rope_node.ctypes.data,
                                                 rope_leaf.ctypes.data, prim.ctypes.data, self._stream()))
+        split_owner = np.zeros(max(n - 1, 1), np.int32)
+        paths = np.zeros(((n + 63) // 64, 5), np.int32)
+        with torch.cuda.device(self.device):
+            _lib.check(self._lib.tknnExportTreeTables(self._h, split_owner.ctypes.data, paths.ctypes.data, self._stream()))
         return {"nodes": nodes[: max(n - 1, 0)], "rope_node": rope_node[: max(n - 1, 0)],
-                "rope_leaf": rope_leaf, "prim_id": prim}
+                "rope_leaf": rope_leaf, "prim_id": prim, "split_owner": split_owner[: max(n - 1, 0)], "block_paths": paths}
 
 
 def trueknn(points, k, start_radius, **kw):

@@ -304,6 +304,52 @@ def test_candidate_thresholds_equal_the_literal_box_test():
         assert np.array_equal((lo <= cand) & (cand <= hi), literal(cand))
 
 
+@pytest.mark.parametrize("n", [2, 3, 64, 65, 129, 20_000])
+def test_lbvh_side_tables(n):
+    """The builder's two side tables (RT-DBSCAN climbs and starts its walks with them): split_owner gives every node's
+    parent in O(1) -- an internal node is a left child iff it is the LAST position of its range --, and block_paths holds,
+    per 64 sorted slots, the deepest internal node whose range holds the whole block and its four nearest ancestors (the
+    root where the path is shorter).  Checked against the exported tree by a walk from the root."""
+    xyz = datasets.gaussian_mixture3d(max(n, 8), components=4, sigma=0.02, seed=19)[:n].copy()
+    if n > 300:
+        xyz[100:300] = xyz[0]  # identical Morton codes
+    eng = _engine()
+    eng.build(xyz)
+    t = eng.export_tree()
+    eng.close()
+    nodes = t["nodes"]
+    split, other = nodes[:, 3].view(np.int32), nodes[:, 7].view(np.int32)
+    i = np.arange(n - 1)
+    first, last = np.minimum(i, other), np.maximum(i, other)
+    owner = t["split_owner"]
+    assert sorted(split.tolist()) == list(range(n - 1)) and np.array_equal(owner[split], i)  # every position splits one node
+    # parents by the rule, against the children each node names
+    left = np.where(first == split, -1, split)  # internal left child (or -1: a leaf)
+    right = np.where(last == split + 1, -1, split + 1)
+    parent = np.full(n - 1, -1)
+    parent[left[left >= 0]] = i[left >= 0]
+    parent[right[right >= 0]] = i[right >= 0]
+    for node in range(1, n - 1):
+        by_rule = owner[node] if node == last[node] else owner[node - 1]
+        assert by_rule == parent[node], node
+    paths = t["block_paths"]
+    assert paths.shape == ((n + 63) // 64, 5)
+    for b in range(paths.shape[0]):
+        lo, hi = 64 * b, min(n - 1, 64 * b + 63)
+        node, trail = 0, [0, 0, 0, 0]
+        while True:  # the walk the table stands for
+            if hi <= split[node] and first[node] != split[node]:
+                nxt = split[node]
+            elif lo > split[node] and last[node] != split[node] + 1:
+                nxt = split[node] + 1
+            else:
+                break
+            trail = trail[1:] + [node]
+            node = nxt
+        assert first[node] <= lo and hi <= last[node]
+        assert paths[b].tolist() == trail + [node], b
+
+
 def test_lbvh_invariants():
     xyz = datasets.gaussian_mixture3d(20_000, components=8, sigma=0.02, seed=9)
     xyz[100:200] = xyz[0]  # identical Morton codes: index tie-break in the radix tree
