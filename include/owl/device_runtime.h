@@ -71,6 +71,11 @@ struct LaunchDesc {  // the single argument of every __raygen__ kernel
   uint32_t num_miss;
   const void *raygen_data;
   const MissRecord *miss;
+  // null, or a permutation of the launch indices (1-D launches): thread t runs launch index order[t].  OptiX promises no
+  // order among the indices of a launch; the host hands out the Morton order of the traced geometry's primitives when a launch
+  // has as many indices as that geometry has primitives (index i = "the query at primitive i" in the neighbour-query
+  // programs this backend is for), so that the threads of a wave walk the same part of the tree
+  const int32_t *order;
 };
 
 // ---- per-thread state in LDS --------------------------------------------------------------
@@ -120,7 +125,8 @@ __device__ __forceinline__ uint3 optixGetLaunchDimensions() {
 }
 __device__ __forceinline__ uint3 optixGetLaunchIndex() {
   const owl::device::LaunchDesc &d = owl::device::state().desc;
-  const uint64_t lin = (uint64_t)blockIdx.x * OWL_RAYGEN_BLOCK + owl::device::tid();
+  uint64_t lin = (uint64_t)blockIdx.x * OWL_RAYGEN_BLOCK + owl::device::tid();
+  if (d.order) lin = (uint64_t)(uint32_t)d.order[lin];
   const uint32_t x = (uint32_t)(lin % d.dims[0]);
   const uint64_t rest = lin / d.dims[0];
   return make_uint3(x, (uint32_t)(rest % d.dims[1]), (uint32_t)(rest / d.dims[1]));

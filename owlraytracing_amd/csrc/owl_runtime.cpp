@@ -79,6 +79,7 @@ struct LaunchDesc {
   uint32_t num_miss;
   const void *raygen_data;
   const MissRecord *miss;
+  const int32_t *order;  // (device_runtime.h)
 };
 struct DeviceBufferVar {  // what an OWL_BUFFER variable expands to (owl_device_buffer.h)
   int32_t type;
@@ -88,7 +89,7 @@ struct DeviceBufferVar {  // what an OWL_BUFFER variable expands to (owl_device_
 };
 static_assert(sizeof(GeomRecord) == 3 * 8 * kMaxRayTypes + 16, "GeomRecord layout");
 static_assert(sizeof(Instance) == 112, "Instance layout");
-static_assert(sizeof(LaunchDesc) == 32, "LaunchDesc layout");
+static_assert(sizeof(LaunchDesc) == 40, "LaunchDesc layout");
 }  // namespace rec
 
 namespace {
@@ -778,6 +779,11 @@ static void refresh_mirrors(Context &c) {
       }
 }
 
+bool launch_order_enabled() {
+  const char *e = getenv("OWL_LAUNCH_ORDER");
+  return !(e && atoi(e) == 0);
+}
+
 void launch(RayGen &rg, int dx, int dy, Params *lp, bool sync) {
   Context &c = *rg.ctx;
   if (!rg.kernel) fail("raygen program not built: call owlBuildPrograms / owlBuildPipeline / owlBuildSBT before launching");
@@ -812,6 +818,23 @@ void launch(RayGen &rg, int dx, int dy, Params *lp, bool sync) {
   desc.num_miss = (uint32_t)c.miss_by_ray_type.size();
   desc.raygen_data = rg.data.ptr;
   desc.miss = (const rec::MissRecord *)c.miss_records.ptr;
+  // The order of a launch's indices is the backend's to choose (LaunchDesc::order): a 1-D launch with as many indices as
+  // the context's one built user geometry group has primitives runs them in that group's Morton order -- in the
+  // neighbour-query programs index i is the query AT primitive i, and 64 neighbouring queries walk the same nodes
+  // (the reference's unchanged sample, 1 M points: 8.8 -> 8.0 ms per launch; the rest is the sample's own intersection
+  // program keeping its k best by insertion into 24-byte records in global memory).  OWL_LAUNCH_ORDER=0: index = thread.
+  desc.order = nullptr;
+  if (dy == 1 && dx > 1 && launch_order_enabled()) {
+    const UserGeomGroup *only = nullptr;
+    int built_groups = 0;
+    for (auto &wg : c.user_groups)
+      if (auto g = wg.lock())
+        if (g->built) {
+          built_groups++;
+          only = g.get();
+        }
+    if (built_groups == 1 && only->bvh.built() && only->bvh.size() == (int64_t)dx) desc.order = only->bvh.view().prim_id;
+  }
   void *args[] = {(void *)&desc};
   launch_kernel(rg.kernel, (uint64_t)dx * (uint64_t)dy, rec::kRaygenBlock, args, s);
   if (lp) {

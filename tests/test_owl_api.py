@@ -126,9 +126,16 @@ def test_program_model_count_closest_hit_and_miss(tmp_path):
 
 
 @pytest.mark.gpu
-def test_reference_device_programs_through_owl_api_match_the_checker(tmp_path):
+@pytest.mark.parametrize("launch_order", ["morton", "thread"])
+def test_reference_device_programs_through_owl_api_match_the_checker(tmp_path, launch_order):
     """The reference's own deviceCode.cu (compiled in place by oracle/build_ref.sh, never copied)
-    driven through owl* by our host driver: frameBuffer equals the CPU checker's, modulo tie order."""
+    driven through owl* by our host driver: frameBuffer equals the CPU checker's, modulo tie order -- with the launch
+    indices handed to the threads in the traced geometry's Morton order (the default for a 1-D launch of as many indices
+    as the geometry has primitives, LaunchDesc::order) and in thread order (OWL_LAUNCH_ORDER=0)."""
+    env = dict(os.environ)
+    env.pop("OWL_LAUNCH_ORDER", None)
+    if launch_order == "thread":
+        env["OWL_LAUNCH_ORDER"] = "0"
     if not os.path.exists(REF_HSACO):
         pytest.skip("oracle/_ref/deviceCode.hsaco not built (no reference tree at build time)")
     _need_driver()
@@ -140,7 +147,7 @@ def test_reference_device_programs_through_owl_api_match_the_checker(tmp_path):
         (tmp_path / "pts.f32").write_bytes(pts.tobytes())
         out = tmp_path / "fb.bin"
         r = subprocess.run([DRIVER, "knn", REF_HSACO, str(tmp_path / "pts.f32"), str(n), str(k), repr(float(np.float32(r0))), str(out)],
-                           capture_output=True, text=True, timeout=600)
+                           capture_output=True, text=True, timeout=600, env=env)
         assert r.returncode == 0, r.stdout + r.stderr
         fb = np.frombuffer(out.read_bytes(), dtype=oracle.NEIGH_DTYPE).reshape(n, k)
         ref = oracle.trueknn(pts, k, float(np.float32(r0)))
