@@ -1055,33 +1055,76 @@ __device__ __forceinline__ void db_min_row(int32_t *cell, int32_t row) {
 // after the unions: every core slot points at its root, and the root learns the smallest ROW of its cluster -- clusters are
 // numbered by that (the spec: ascending smallest core index).  A wave's slots mostly share one root: one atomic per wave
 // and root, not per point.
+// Four consecutive slots per thread, their words fetched as one 16-byte load per array: a thread with one slot has one
+// 4-byte load in flight per step of its chain (flag -> parent -> parent's parent -> row), and half a million such threads on
+// the device do not fill the memory system (0.15 ms for 0.2 GB).
+constexpr int kDbPer = 4;
 __global__ void __launch_bounds__(kDbBlock) db_flatten_kernel(DbArgs a, int32_t *zero) {
-  const int32_t t = blockIdx.x * kDbBlock + threadIdx.x;
-  if (t < a.bvh.n) zero[t] = 0;  // the root flags of the next launch (the group list lived here)
-  const bool core = t < a.bvh.n && a.core_sorted[t];
-  int32_t root = -1, row = 0x7fffffff;
-  if (core) {
-    root = uf_find(a.parent, t);
-    __hip_atomic_store(a.parent + t, root, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    row = a.bvh.prim_id[t];
+  const int32_t n = a.bvh.n;
+  const long long t0 = ((long long)blockIdx.x * kDbBlock + threadIdx.x) * kDbPer;
+  int32_t par[kDbPer], prim[kDbPer];
+  bool core[kDbPer];
+  if (t0 + kDbPer <= n) {
+    const int4 p4 = *reinterpret_cast<const int4 *>(a.parent + t0), r4 = *reinterpret_cast<const int4 *>(a.bvh.prim_id + t0);
+    const uchar4 c4 = *reinterpret_cast<const uchar4 *>(a.core_sorted + t0);
+    par[0] = p4.x, par[1] = p4.y, par[2] = p4.z, par[3] = p4.w;
+    prim[0] = r4.x, prim[1] = r4.y, prim[2] = r4.z, prim[3] = r4.w;
+    core[0] = c4.x != 0, core[1] = c4.y != 0, core[2] = c4.z != 0, core[3] = c4.w != 0;
+#pragma unroll
+    for (int k = 0; k < kDbPer; k++) zero[t0 + k] = 0;  // the root flags of the next launch (the group list lived here; its place is 16-byte aligned only if n is a multiple of four)
+  } else {
+#pragma unroll
+    for (int k = 0; k < kDbPer; k++) {
+      const bool in = t0 + k < n;
+      const long long t = in ? t0 + k : 0;
+      par[k] = a.parent[t], prim[k] = a.bvh.prim_id[t], core[k] = in && a.core_sorted[t] != 0;
+      if (in) zero[t] = 0;
+    }
+  }
+  // (plain loads and stores: the unions are over -- what this launch reads is final or, where another lane's store below has
+  // or has not arrived, a root or an older ancestor in the same tree: the walk ends at the root either way)
+  int32_t up[kDbPer], root[kDbPer];
+#pragma unroll
+  for (int k = 0; k < kDbPer; k++) up[k] = a.parent[core[k] ? par[k] : 0];
+#pragma unroll
+  for (int k = 0; k < kDbPer; k++) {
+    root[k] = par[k];
+    if (core[k] && up[k] != par[k]) {
+      int32_t x = up[k], p = a.parent[x];
+      while (p != x) x = p, p = a.parent[x];
+      root[k] = x;
+    }
+    if (core[k] && root[k] != par[k]) a.parent[t0 + k] = root[k];
+  }
+  // the thread's slots of its first core slot's root as one (root, smallest row); the others (a boundary between clusters
+  // inside four slots) send their own
+  int32_t my_root = -1, row = 0x7fffffff;
+#pragma unroll
+  for (int k = 0; k < kDbPer; k++) {
+    if (!core[k]) continue;
+    if (my_root < 0) my_root = root[k];
+    if (root[k] == my_root)
+      row = min(row, prim[k]);
+    else
+      db_min_row(a.min_row + root[k], prim[k]);
   }
   const int lane = threadIdx.x & 63;
   // the wave's two most common cases first -- one root for all its slots, or two -- as one atomic each; slots of further
   // roots (sparse regions: many small clusters per wave, hardly two slots on one address) send their own
-  bool pending = core;
+  bool pending = my_root >= 0;
   for (int round = 0; round < 2; round++) {
     const unsigned long long todo = __ballot(pending);
     if (!todo) break;
     const int j = __ffsll((long long)todo) - 1;
-    const int32_t r_j = __shfl(root, j);
-    const bool same = pending && root == r_j;
+    const int32_t r_j = __shfl(my_root, j);
+    const bool same = pending && my_root == r_j;
     int32_t m = same ? row : 0x7fffffff;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) m = min(m, __shfl_xor(m, off));
     if (lane == j) db_min_row(a.min_row + r_j, m);
     pending = pending && !same;
   }
-  if (pending) db_min_row(a.min_row + root, row);
+  if (pending) db_min_row(a.min_row + my_root, row);
 }
 // roots flag their cluster's smallest row; an exclusive scan over the rows then numbers the clusters
 __global__ void __launch_bounds__(kDbBlock) db_root_kernel(DbArgs a, int32_t *is_first_row) {
@@ -1131,12 +1174,37 @@ __global__ void __launch_bounds__(kDbBlock) db_label_kernel(DbArgs a, const int3
   __syncthreads();
   uint32_t node_tests = 0, point_tests = 0;
   if ((int)blockIdx.x >= walk_blocks) {
-    const long long t = (long long)(blockIdx.x - walk_blocks) * kDbBlock + threadIdx.x;
-    if (t < a.bvh.n) {
-      const int32_t row = a.bvh.prim_id[t];
-      const uint8_t is_core = a.core_sorted[t];
-      if (a.core) a.core[row] = is_core;
-      if (is_core) a.labels[row] = a.rank[a.min_row[uf_find(a.parent, (int32_t)t)]];  // (mostly one step: db_flatten_kernel has pointed the slots at their roots)
+    // four consecutive slots per thread (db_flatten_kernel: 16-byte loads, four chains in flight); a core slot's parent IS its
+    // root since that kernel
+    const int32_t n = a.bvh.n;
+    const long long t0 = ((long long)(blockIdx.x - walk_blocks) * kDbBlock + threadIdx.x) * kDbPer;
+    int32_t row[kDbPer], root[kDbPer];
+    bool in[kDbPer], core[kDbPer];
+    if (t0 + kDbPer <= n) {
+      const int4 p4 = *reinterpret_cast<const int4 *>(a.parent + t0), r4 = *reinterpret_cast<const int4 *>(a.bvh.prim_id + t0);
+      const uchar4 c4 = *reinterpret_cast<const uchar4 *>(a.core_sorted + t0);
+      root[0] = p4.x, root[1] = p4.y, root[2] = p4.z, root[3] = p4.w;
+      row[0] = r4.x, row[1] = r4.y, row[2] = r4.z, row[3] = r4.w;
+      core[0] = c4.x != 0, core[1] = c4.y != 0, core[2] = c4.z != 0, core[3] = c4.w != 0;
+      in[0] = in[1] = in[2] = in[3] = true;
+    } else {
+#pragma unroll
+      for (int k = 0; k < kDbPer; k++) {
+        in[k] = t0 + k < n;
+        const long long t = in[k] ? t0 + k : 0;
+        root[k] = a.parent[t], row[k] = a.bvh.prim_id[t], core[k] = in[k] && a.core_sorted[t] != 0;
+      }
+    }
+    int32_t first_row[kDbPer], number[kDbPer];
+#pragma unroll
+    for (int k = 0; k < kDbPer; k++) first_row[k] = a.min_row[core[k] ? root[k] : 0];
+#pragma unroll
+    for (int k = 0; k < kDbPer; k++) number[k] = a.rank[core[k] ? first_row[k] : 0];
+#pragma unroll
+    for (int k = 0; k < kDbPer; k++) {
+      if (!in[k]) continue;
+      if (a.core) a.core[row[k]] = core[k];
+      if (core[k]) a.labels[row[k]] = number[k];
     }
   } else {
     const long long total = (long long)*n_pending;
@@ -1522,7 +1590,8 @@ void Engine::dbscan(float eps, int min_pts, int32_t *d_labels, uint8_t *d_core, 
   }
   OWLMI_HIP(hipEventRecord(ev_e_, s));
   if (per_point) OWLMI_HIP(hipMemsetAsync(a.min_row, 0x7f, (size_t)n * sizeof(int32_t), s));  // 0x7f7f7f7f: above every row (else: db_group_kernel)
-  hipLaunchKernelGGL(db_flatten_kernel, dim3(blocks), dim3(kDbBlock), 0, s, a, is_root);
+  const unsigned blocks_per = (unsigned)(((n + kDbPer - 1) / kDbPer + kDbBlock - 1) / kDbBlock);  // kDbPer slots per thread
+  hipLaunchKernelGGL(db_flatten_kernel, dim3(blocks_per), dim3(kDbBlock), 0, s, a, is_root);
   hipLaunchKernelGGL(db_root_kernel, dim3(blocks), dim3(kDbBlock), 0, s, a, is_root);
   OWLMI_HIP(hipGetLastError());
   OWLMI_HIP(hipcub::DeviceScan::ExclusiveSum(scan_tmp, scan_bytes, is_root, a.rank, (int)n, s));
@@ -1532,7 +1601,7 @@ void Engine::dbscan(float eps, int min_pts, int32_t *d_labels, uint8_t *d_core, 
   OWLMI_HIP(hipMemcpyAsync(&last[1], is_root + (n - 1), 4, hipMemcpyDeviceToHost, s));
   OWLMI_HIP(hipEventRecord(ev_f_, s));
   if (side) OWLMI_HIP(hipStreamWaitEvent(s, ev_side_b_, 0));
-  hipLaunchKernelGGL(db_label_kernel, dim3(walk_grid + blocks), dim3(kDbBlock), 0, s, a, not_core, counters_ + 19, (int)walk_grid,
+  hipLaunchKernelGGL(db_label_kernel, dim3(walk_grid + blocks_per), dim3(kDbBlock), 0, s, a, not_core, counters_ + 19, (int)walk_grid,
                      side ? border_lists : (const int32_t *)nullptr, border_per, (long long)n);
   OWLMI_HIP(hipGetLastError());
   OWLMI_HIP(hipEventRecord(e1, s));
