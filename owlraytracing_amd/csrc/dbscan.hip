@@ -391,6 +391,58 @@ __global__ void __launch_bounds__(kDbBlock) db_core_pos_kernel(DbArgs a, const i
     if (others) *n_others = (unsigned long long)(a.bvh.n - n_core);
   }
 }
+// The same three steps without a rank per slot (tknnDbscan; a library sum over the n flags took 0.05 ms and a 40 MB array
+// written once and read twice): a count of the core flags per workgroup of 256 slots, a sum over those n / 256 counts, and
+// the two kernels below find a slot's rank as its workgroup's place + the core slots before it in the workgroup.
+__device__ __forceinline__ int32_t db_rank_in_block(bool flag, int32_t block_place, int32_t *wave_count, int32_t &block_total) {
+  const unsigned long long m = __ballot(flag);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) wave_count[wave] = __popcll(m);
+  __syncthreads();
+  int32_t r = block_place;
+  block_total = 0;
+  for (int w = 0; w < kDbBlock / 64; w++) {
+    if (w < wave) r += wave_count[w];
+    block_total += wave_count[w];
+  }
+  return r + __popcll(m & ((1ull << lane) - 1ull));
+}
+__global__ void __launch_bounds__(kDbBlock) db_flag_count_kernel(DbArgs a, int32_t *block_count) {
+  __shared__ int32_t wave_count[kDbBlock / 64];
+  const int32_t t = blockIdx.x * kDbBlock + threadIdx.x;
+  int32_t total;
+  (void)db_rank_in_block(t < a.bvh.n && a.core_sorted[t] != 0, 0, wave_count, total);
+  if (threadIdx.x == 0) block_count[blockIdx.x] = total;
+}
+__global__ void __launch_bounds__(kDbBlock) db_core_pos_blocks_kernel(DbArgs a, const int32_t *block_place, int32_t *pos, int32_t *others,
+                                                                      unsigned long long *n_others) {
+  __shared__ int32_t wave_count[kDbBlock / 64];
+  const int32_t t = blockIdx.x * kDbBlock + threadIdx.x;
+  const bool in = t < a.bvh.n, is_core = in && a.core_sorted[t] != 0;
+  int32_t total;
+  const int32_t r = db_rank_in_block(is_core, block_place[blockIdx.x], wave_count, total);
+  if (!in) return;
+  if (is_core)
+    pos[r] = t;
+  else if (others)
+    others[t - r] = t;
+  if (t == a.bvh.n - 1) {
+    const int32_t n_core = r + (is_core ? 1 : 0);
+    pos[n_core] = 0x7f7f7f7f;  // "none" (clamped below): the one place a slot behind the last core point looks at
+    if (others) *n_others = (unsigned long long)(a.bvh.n - n_core);
+  }
+}
+__global__ void __launch_bounds__(kDbBlock) db_next_core_blocks_kernel(DbArgs a, const int32_t *block_place, const int32_t *pos, int32_t *next_core) {
+  __shared__ int32_t wave_count[kDbBlock / 64];
+  const int32_t t = blockIdx.x * kDbBlock + threadIdx.x;
+  const bool in = t < a.bvh.n;
+  int32_t total;
+  const int32_t r = db_rank_in_block(in && a.core_sorted[t] != 0, block_place[blockIdx.x], wave_count, total);
+  if (!in) return;
+  const int32_t v = pos[r];  // a slot after the last core point has rank = number of core points: pos[] holds "none" there
+  next_core[t] = v < a.bvh.n ? v : a.bvh.n;
+  if (t == a.bvh.n - 1) next_core[a.bvh.n] = a.bvh.n;
+}
 __global__ void __launch_bounds__(kDbBlock) db_next_core_kernel(DbArgs a, const int32_t *rank, const int32_t *pos,
                                                                 int32_t *next_core) {
   const int32_t t = blockIdx.x * kDbBlock + threadIdx.x;
@@ -503,32 +555,57 @@ __device__ __forceinline__ void box_box_dist2(const float *alo, const float *ahi
   near2 = g;
 }
 
-struct DbIsGroup {
-  __host__ __device__ bool operator()(int32_t ref) const { return ref != LBVH_END; }
-};
 // per slot: the group's reference (node, or ~slot of a single point) at the group's first slot if the group has a core
-// point, LBVH_END everywhere else -- compacted into the list, in slot order, by a select.  The core-flag kernel has left
-// every point's group in group_of (it walks the point's root path anyway).
+// point, LBVH_END everywhere else -- compacted into the list, in slot order, in three steps: this kernel counts each
+// workgroup's entries, an exclusive sum over those n / 256 counts gives the workgroups' places, db_group_list_kernel writes
+// the entries (a library select over the n slots took 0.09 ms of a 3 ms call).  The core-flag
+// kernel has left every point's group in group_of (it walks the point's root path anyway).
 // (The kernel also fills, as it streams by, what later launches want filled: a fill is a launch of its own otherwise.)
-__global__ void __launch_bounds__(kDbBlock) db_group_kernel(DbArgs a, int32_t *group_at, int32_t *fill_uni, int32_t *fill_min_row) {
+__global__ void __launch_bounds__(kDbBlock) db_group_kernel(DbArgs a, int32_t *group_at, int32_t *fill_uni, int32_t *fill_min_row,
+                                                            int32_t *block_count) {
+  __shared__ int32_t wave_count[kDbBlock / 64];
   const LbvhView &bvh = a.bvh;
   const int32_t t = blockIdx.x * kDbBlock + threadIdx.x;
-  if (t >= bvh.n) return;
-  fill_uni[t] = -1;                 // db_uniform_kernel: nobody has arrived
-  fill_min_row[t] = 0x7f7f7f7f;     // db_flatten_kernel: above every row
-  const int32_t g = a.group_of[t];
-  const bool leads = g >= 0 || g == ~t;
-  const int32_t first = leads ? t : ~g;
-  const int32_t s = a.next_core[first];
-  // s < t, both core, one group: united by a plain store -- these are the call's first unions, every slot is still its own
-  // root, s stays one throughout this kernel (only later slots are hooked, under it), and parent[t] is written by nobody else
-  if (a.core_sorted[t] && s != t && !(a.diag & 4)) a.parent[t] = s;
   int32_t out = LBVH_END;
-  if (leads) {
-    const int32_t last = g >= 0 ? lbvh_last(g, bvh.nodes[g].other) : t;
-    if (s <= last) out = g;
+  if (t < bvh.n) {
+    fill_uni[t] = -1;              // db_uniform_kernel: nobody has arrived
+    fill_min_row[t] = 0x7f7f7f7f;  // db_flatten_kernel: above every row
+    const int32_t g = a.group_of[t];
+    const bool leads = g >= 0 || g == ~t;
+    const int32_t first = leads ? t : ~g;
+    const int32_t s = a.next_core[first];
+    // s < t, both core, one group: united by a plain store -- these are the call's first unions, every slot is still its
+    // own root, s stays one throughout this kernel (only later slots are hooked, under it), and parent[t] is written by
+    // nobody else
+    if (a.core_sorted[t] && s != t && !(a.diag & 4)) a.parent[t] = s;
+    if (leads) {
+      const int32_t last = g >= 0 ? lbvh_last(g, bvh.nodes[g].other) : t;
+      if (s <= last) out = g;
+    }
+    group_at[t] = out;
   }
-  group_at[t] = out;
+  const unsigned long long m = __ballot(out != LBVH_END);
+  if ((threadIdx.x & 63) == 0) wave_count[threadIdx.x >> 6] = __popcll(m);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int32_t c = 0;
+    for (int w = 0; w < kDbBlock / 64; w++) c += wave_count[w];
+    block_count[blockIdx.x] = c;
+  }
+}
+__global__ void __launch_bounds__(kDbBlock) db_group_list_kernel(DbArgs a, const int32_t *group_at, const int32_t *block_place, int32_t *groups,
+                                                                 unsigned long long *total) {
+  __shared__ int32_t wave_count[kDbBlock / 64];
+  const int32_t t = blockIdx.x * kDbBlock + threadIdx.x;
+  const int32_t g = t < a.bvh.n ? group_at[t] : LBVH_END;
+  const unsigned long long m = __ballot(g != LBVH_END);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) wave_count[wave] = __popcll(m);
+  __syncthreads();
+  int32_t place = block_place[blockIdx.x];
+  for (int w = 0; w < wave; w++) place += wave_count[w];
+  if (g != LBVH_END) groups[place + __popcll(m & ((1ull << lane) - 1ull))] = g;
+  if (blockIdx.x == gridDim.x - 1 && threadIdx.x == kDbBlock - 1) *total = (unsigned long long)(place + __popcll(m));  // the list's length
 }
 
 // Between the two passes of the group-union kernel: which tree nodes hold core points of ONE set only?  After the first pass
@@ -1416,16 +1493,14 @@ void Engine::dbscan(float eps, int min_pts, int32_t *d_labels, uint8_t *d_core, 
   const int64_t n = bvh_.size();
   // scratch: core flags per slot, parent, root flags, ranks, next_core (+ two sentinels), smallest rows
   const size_t min_row_at = ((size_t)n * 17 + 8 + 15) / 16 * 16;
-  const size_t need = (min_row_at + (size_t)n * 16 + 255) / 256 * 256;  // ... the list of the slots that are not core, their core neighbours
-  size_t scan_bytes = 0, select_bytes = 0;
+  const size_t need = (min_row_at + (size_t)n * 16 + ((size_t)n / kDbBlock + 2) * 8 + 255) / 256 * 256;  // ... the list of the slots that are not core, their core neighbours
+  size_t scan_bytes = 0;
   OWLMI_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, (int32_t *)nullptr, (int32_t *)nullptr, (int)n, s));
   {
     size_t flag_scan_bytes = 0;
     OWLMI_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, flag_scan_bytes, DbFlagIter(nullptr, DbFlagOf()), (int32_t *)nullptr, (int)n, s));
     scan_bytes = std::max(scan_bytes, flag_scan_bytes);
   }
-  OWLMI_HIP(hipcub::DeviceSelect::If(nullptr, select_bytes, (int32_t *)nullptr, (int32_t *)nullptr, (unsigned long long *)nullptr, (int)n, DbIsGroup(), s));
-  scan_bytes = std::max(scan_bytes, select_bytes);
   if (need + scan_bytes > wave_ws_bytes_) {
     if (wave_ws_) (void)hipFree(wave_ws_);
     wave_ws_ = nullptr;
@@ -1451,6 +1526,7 @@ void Engine::dbscan(float eps, int min_pts, int32_t *d_labels, uint8_t *d_core, 
   a.min_row = (int32_t *)(ws + min_row_at);
   int32_t *not_core = a.min_row + n;  // in slot order; its length in counters_[19]
   int32_t *uni = not_core + 2 * (size_t)n;  // db_uniform_kernel's per-node sets (behind border_lists)
+  int32_t *block_places = uni + n;          // per workgroup of 256 slots: its listed groups; behind them, their places in the list
   int32_t *border_lists = not_core + n;  // `border_per` words per listed point, if they fit n words: a count and the core neighbours
   const int border_per = std::max(2, min_pts);
   const bool side = !core_label && !(getenv("TKNN_DB_SIDE") && atoi(getenv("TKNN_DB_SIDE")) == 0);  // (0: measurements without the side stream)
@@ -1490,11 +1566,11 @@ void Engine::dbscan(float eps, int min_pts, int32_t *d_labels, uint8_t *d_core, 
   {
     // next_core: flags -> exclusive sum (rank of a slot among the core slots) -> slot of the r-th core
     // point -> first core slot at or after each slot.  is_root / rank are free until the unions are done.
-    int32_t *core_rank = is_root, *pos = a.rank;
-    const unsigned blocks1 = (unsigned)((n + 1 + kDbBlock - 1) / kDbBlock);
-    OWLMI_HIP(hipcub::DeviceScan::ExclusiveSum(scan_tmp, scan_bytes, DbFlagIter(a.core_sorted, DbFlagOf()), core_rank, (int)n, s));
-    hipLaunchKernelGGL(db_core_pos_kernel, dim3(blocks), dim3(kDbBlock), 0, s, a, core_rank, pos, core_label ? (int32_t *)nullptr : not_core, counters_ + 19);
-    hipLaunchKernelGGL(db_next_core_kernel, dim3(blocks1), dim3(kDbBlock), 0, s, a, core_rank, pos, next_core);
+    int32_t *pos = a.rank;
+    hipLaunchKernelGGL(db_flag_count_kernel, dim3(blocks), dim3(kDbBlock), 0, s, a, block_places);
+    OWLMI_HIP(hipcub::DeviceScan::ExclusiveSum(scan_tmp, scan_bytes, block_places, block_places + blocks, (int)blocks, s));
+    hipLaunchKernelGGL(db_core_pos_blocks_kernel, dim3(blocks), dim3(kDbBlock), 0, s, a, block_places + blocks, pos, core_label ? (int32_t *)nullptr : not_core, counters_ + 19);
+    hipLaunchKernelGGL(db_next_core_blocks_kernel, dim3(blocks), dim3(kDbBlock), 0, s, a, block_places + blocks, pos, next_core);
   }
   if (side) {  // the walks of the points that are not core, beside everything up to the label kernel
     OWLMI_HIP(hipEventRecord(ev_side_a_, s));
@@ -1535,8 +1611,9 @@ void Engine::dbscan(float eps, int min_pts, int32_t *d_labels, uint8_t *d_core, 
     a.chunk = getenv("TKNN_DB_CHUNK") ? std::max(1, atoi(getenv("TKNN_DB_CHUNK"))) : 64;
     a.short_way = getenv("TKNN_DB_SHORT") ? atoi(getenv("TKNN_DB_SHORT")) : 1;
     a.scan_budget = getenv("TKNN_DB_SCAN") ? std::max(0, atoi(getenv("TKNN_DB_SCAN"))) : 12;
-    hipLaunchKernelGGL(db_group_kernel, dim3(blocks), dim3(kDbBlock), 0, s, a, group_at, uni, a.min_row);
-    OWLMI_HIP(hipcub::DeviceSelect::If(scan_tmp, scan_bytes, group_at, groups, n_groups, (int)n, DbIsGroup(), s));
+    hipLaunchKernelGGL(db_group_kernel, dim3(blocks), dim3(kDbBlock), 0, s, a, group_at, uni, a.min_row, block_places);
+    OWLMI_HIP(hipcub::DeviceScan::ExclusiveSum(scan_tmp, scan_bytes, block_places, block_places + blocks, (int)blocks, s));
+    hipLaunchKernelGGL(db_group_list_kernel, dim3(blocks), dim3(kDbBlock), 0, s, a, group_at, block_places + blocks, groups, n_groups);
     // persistent lanes: as many workgroups as the device holds at once (the list's length is known on the device only)
     // (per engine: the CU count and the occupancy are those of THIS engine's device)
     if (db_union_resident_ == 0) {
