@@ -298,7 +298,7 @@ def main():
         line = trueknn_line(args, info, infos, value, ms_per_step, n_total, n_local, world, sharded, r0, tiles)
     line["scaling"] = args.scaling if sharded else "weak"
     line.update(extra)
-    failed = False
+    checks = {}  # named result checks of this run; ANY red one fails the run (run_failed)
     if not sharded:
         line["build_ms"] = float(build_info["build_ms"])
         line["tree_bytes"] = int(build_info["device_bytes"])
@@ -324,7 +324,7 @@ def main():
         # BASELINE config 3 in the same run (the driver only runs the default command): timed like the steps
         # above, per-kernel rooflines, a sampled eps-ball parity check by the CPU spec
         db_failed, line["dbscan_config3"] = dbscan_config3_leg(args, eng, dev)
-        failed = failed or db_failed
+        checks["dbscan_config3"] = not db_failed
     if rank == 0 and not sharded and not args.no_cpu_baseline:
         if dbscan:
             cb, ref, m = cpu_baseline_dbscan(xyz_host, eps32, args.min_pts)
@@ -332,7 +332,7 @@ def main():
             if m == n_total:  # the whole set went through the checker: compare the benchmarked run with it
                 ok = (np.array_equal(out["labels"].cpu().numpy(), ref["labels"]) and np.array_equal(out["core"].cpu().numpy(), ref["core"]))
                 line["parity_spot_check"] = "labels and core flags of all %d points equal the CPU spec's" % m if ok else "MISMATCH"
-                failed = not ok
+                checks["parity_spot_check"] = ok
             else:
                 # core flags of the first m points are density-dependent: no comparison on a share; the full-size parity
                 # test is tests/test_dbscan.py::test_config3_full_size (-m gpu)
@@ -346,7 +346,8 @@ def main():
                   and np.array_equal(out["dist"][ql].cpu().numpy(), ref["dist"][q])
                   and np.array_equal(out["intersections"][ql].cpu().numpy(), ref["intersections"][q]))
             line["parity_spot_check"] = "bit-exact on %d sampled rows" % len(q) if ok else "MISMATCH"
-            failed = not ok
+            checks["parity_spot_check"] = ok
+    failed = run_failed(checks)
     if failed:
         line["value"] = None  # a wrong result has no throughput
     if rank == 0:
@@ -355,6 +356,12 @@ def main():
         dist.destroy_process_group()
     if failed:
         sys.exit(1)
+
+
+def run_failed(checks):
+    """A run fails if ANY of its named checks is red (the kNN spot check used to overwrite the verdict of the
+    dbscan_config3 leg, so a wrong DBSCAN result left exit status 0 and the headline value in place)."""
+    return any(not ok for ok in checks.values())
 
 
 def trueknn_line(args, info, infos, value, ms_per_step, n_total, n_local, world, sharded, r0, tiles):

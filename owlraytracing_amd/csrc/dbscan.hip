@@ -318,9 +318,13 @@ __device__ __forceinline__ void db_core_body(const DbArgs &a, int32_t t, uint32_
           // a node inside the sphere is counted, not walked
           float far2, near2;
           box_dist2(nd, q, far2, near2);
-          const int32_t last = lbvh_last(at, nd.other);
-          if (far2 <= a.eps_in2 && last < clean_end) {
-            cnt += last - lbvh_first(at, nd.other) + 1;
+          const int32_t first = lbvh_first(at, nd.other), last = lbvh_last(at, nd.other);
+          // (a node that holds my own slot while a subtree is being stepped over is an ANCESTOR of that subtree -- the subtree
+          // itself is stepped over before it gets here, its descendants are never reached --: its points were counted in part
+          // already, so it is walked, not added whole)
+          const bool over_skipped = skip != LBVH_END && first <= t && t <= last;
+          if (far2 <= a.eps_in2 && last < clean_end && !over_skipped) {
+            cnt += last - first + 1;
             at = rope;
             continue;
           }

@@ -297,6 +297,72 @@ __device__ __forceinline__ void t_clean16(uint32_t &kd, uint32_t &ki, int tl) {
   t_exchange(kd, ki, t_dpp<0x4e>(kd), t_dpp<0x4e>(ki), up2);
   t_exchange(kd, ki, t_dpp<0xb1>(kd), t_dpp<0xb1>(ki), up1);
 }
+// ---- the same network on ONE 32-bit word per lane (round 4) ------------------------------------------------------------
+// A 64-bit exchange is two DPP moves, a 64-bit compare, a mask xor and two selects -- six slow instructions and their wait
+// states, ten times per sort: the sorting networks were a fifth of the packet kernel's vector time.  On one word the
+// exchange is a DPP move and ONE v_med3_u32: med3(a, b, 0) = min(a, b) for the lower lane of a pair, med3(a, b, ~0) =
+// max(a, b) for the upper one (the third operand is a constant of the lane).  The word is the key's order WITHOUT its last
+// four bits, which carry the lane the key came from; the caller fetches the exact key from there afterwards and checks that
+// the dropped bits could not have mattered (t_sorted_row).
+__device__ __forceinline__ uint32_t t_med3_u32(uint32_t a, uint32_t b, uint32_t c) {
+  uint32_t out;
+  asm("v_med3_u32 %0, %1, %2, %3" : "=v"(out) : "v"(a), "v"(b), "v"(c));
+  return out;
+}
+// partner lane ^ 4, lower lane keeps the smaller word: the two halves as one masked min and one masked max (bank = four
+// consecutive lanes of a row; row_shl:4 reads four lanes up, row_shr:4 four lanes down).  s_nop: a DPP operand written by the
+// instruction before it needs two wait states, and the compiler does not look into inline assembly for that.
+__device__ __forceinline__ uint32_t t_exchange_xor4_u32(uint32_t v) {
+  uint32_t out;
+  asm("s_nop 1\n\t"
+      "v_min_u32_dpp %0, %1, %1 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+      "v_max_u32_dpp %0, %1, %1 row_shr:4 row_mask:0xf bank_mask:0xa"
+      : "=&v"(out)
+      : "v"(v));
+  return out;
+}
+__device__ __forceinline__ void t_sort16_u32(uint32_t &v, int tl) {
+  const uint32_t c1 = 0u - ((uint32_t)tl & 1u), c2 = 0u - (((uint32_t)tl >> 1) & 1u), c4 = 0u - (((uint32_t)tl >> 2) & 1u),
+                 c8 = 0u - (((uint32_t)tl >> 3) & 1u);
+  v = t_med3_u32(v, t_dpp<0xb1>(v), c1);   // pairs
+  v = t_med3_u32(v, t_dpp<0x1b>(v), c2);   // mirror within 4
+  v = t_med3_u32(v, t_dpp<0xb1>(v), c1);
+  v = t_med3_u32(v, t_dpp<0x141>(v), c4);  // mirror within 8
+  v = t_med3_u32(v, t_dpp<0x4e>(v), c2);   // xor 2
+  v = t_med3_u32(v, t_dpp<0xb1>(v), c1);
+  v = t_med3_u32(v, t_dpp<0x140>(v), c8);  // mirror within 16
+  v = t_exchange_xor4_u32(v);
+  v = t_med3_u32(v, t_dpp<0x4e>(v), c2);
+  v = t_med3_u32(v, t_dpp<0xb1>(v), c1);
+}
+// Sixteen (squared distance, index) keys, one per lane of a team (`have`: my lane has one), as the sorted row of
+// (IEEE distance, index) keys the lists take -- KNN_EMPTY_KEY past the last.  `fetch(lane)` returns the key lane `lane` of
+// my team came with.  The sort runs on (bits of d2 without their last four | lane); it is the order of the full keys unless
+// two neighbours of the outcome are closer than that can tell -- their truncated words equal or one apart, which covers
+// d2 values less than sixteen ulps apart: exact duplicates, the ties of quantised data, and the pairs of different squares
+// whose ROUNDED roots coincide (the pre-image of one rounded root spans three floats), for which the index decides -- or a
+// square overflowed to infinity (its root is beyond the empty key, which the word order does not know).  Then the exact
+// network runs instead (uniform 10 M points: once in 10^4 rows).
+template <typename Fetch>
+__device__ __forceinline__ void t_sorted_row(uint32_t d2_bits, uint32_t id, bool have, int tl, Fetch fetch, uint32_t &kd, uint32_t &ki) {
+  uint32_t w = have ? ((d2_bits & ~15u) | (uint32_t)tl) : (0xfffffff0u | (uint32_t)tl);
+  t_sort16_u32(w, tl);
+  const uint32_t before = t_team_shr1(w);
+  const bool real = w < 0xfffffff0u;
+  const bool unsure = real & (((tl > 0) & ((w >> 4) - (before >> 4) <= 1u)) | (w >= 0x7f7ffff0u));
+  if (__builtin_expect(__ballot(unsure) == 0ull, 1)) {
+    const unsigned long long key = fetch((int)(w & 15u));
+    const float dist = knn_sqrt(__uint_as_float((uint32_t)(key >> 32)));
+    kd = real ? __float_as_uint(dist) : 0x7f7fffffu;
+    ki = real ? (uint32_t)key : 0u;
+  } else {
+    const float dist = knn_sqrt(__uint_as_float(d2_bits));
+    kd = have ? __float_as_uint(dist) : 0x7f7fffffu;
+    ki = have ? id : 0u;
+    t_sort16(kd, ki, tl);
+  }
+}
+
 // Candidates that pass a team's gate are not inserted one lock-step round each: they wait in the team's LDS buffer as
 // (squared distance, index) and are MERGED into the sorted list sixteen at a time.  `buf`: my team's buffer, `fill`: how
 // many wait (the same in the team's lanes).  Per row of sixteen: the IEEE root (sixteen instructions, once per row and not
@@ -315,9 +381,8 @@ __device__ __forceinline__ void t_merge_rows(uint32_t (&bd)[NREG], uint32_t (&bi
     const uint32_t at = 16u * (uint32_t)row + (uint32_t)tl;
     const bool have = at < fill;
     const unsigned long long key = have ? buf[at] : 0ull;
-    const float dist = knn_sqrt(__uint_as_float((uint32_t)(key >> 32)));
-    uint32_t kd = have ? __float_as_uint(dist) : 0x7f7fffffu, ki = have ? (uint32_t)key : 0u;  // KNN_EMPTY_KEY past the end
-    t_sort16(kd, ki, tl);
+    uint32_t kd, ki;  // the row, sorted: (IEEE distance, index), KNN_EMPTY_KEY past the end
+    t_sorted_row((uint32_t)(key >> 32), (uint32_t)key, have, tl, [&](int from) { return buf[16 * row + from]; }, kd, ki);
 #pragma unroll
     for (int j = 0; j < NREG; j++) {
       const uint32_t od = t_dpp<0x140>(kd), oi = t_dpp<0x140>(ki);  // the row's key 15 - tl
@@ -492,7 +557,6 @@ __device__ __forceinline__ void team_pass(const TeamArgs &a, const TeamLds &L, i
     // candidate mask: the slot of a candidate used to come from an LDS atomic -- a round trip through the LDS pipe in the
     // middle of every block step that had a candidate, in a kernel that is bound by the latency of such chains
     uint32_t fill_n = 0;
-    auto sort16 = [&](uint32_t &kd, uint32_t &ki) { t_sort16(kd, ki, tl); };
     auto merge_buffer = [&]() {
       t_wave_sync();
       t_merge_rows<NREG>(bd, bi, left_out, full, L.cand + team * kCandCap, fill_n, tl);
@@ -577,9 +641,13 @@ __device__ __forceinline__ void team_pass(const TeamArgs &a, const TeamLds &L, i
       cnt = t_count(cnt, __ballot(in));
       bool cand = in && (p.id != t_qid);
       if (TKNN_DIAG_BUILD && (a.diag & 1)) cand = false;
-      bd[0] = cand ? __float_as_uint(knn_sqrt(t_dist2(dx, dy, dz))) : 0x7f7fffffu;
-      bi[0] = cand ? (uint32_t)p.id : 0u;
-      sort16(bd[0], bi[0]);
+      // (the squares go through the team's candidate buffer, empty at this point, so that the sorted lanes can fetch them)
+      const uint32_t d2_bits = __float_as_uint(t_dist2(dx, dy, dz));
+      unsigned long long *my_buf = L.cand + team * kCandCap;
+      my_buf[tl] = ((unsigned long long)d2_bits << 32) | (uint32_t)p.id;
+      t_wave_sync();
+      t_sorted_row(d2_bits, (uint32_t)p.id, cand, tl, [&](int from) { return my_buf[from]; }, bd[0], bi[0]);
+      t_wave_sync();  // (read: the first candidates may overwrite them)
       tau2 = knn_gate_from_worst(kth_dist());  // k > 16: the second register is still empty, the gate stays open
     };
     TP_LAP(0);

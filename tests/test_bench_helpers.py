@@ -87,3 +87,15 @@ def test_sharded_infos_of_two_calls_merge_into_one_solve():
     assert m["dominant_kernel_launches"] == 2 and abs(m["dominant_kernel_ms"] - 1.45) < 1e-12
     both = ShardedTrueKNN._merge_infos(a, b, 0)  # interior + boundary phases: unfinished queries of both count
     assert both["unfinished"] == 7 and both["total_active_rounds"] == 328
+
+
+def test_one_red_check_fails_the_run_whatever_the_others_say():
+    """a mismatch in the dbscan_config3 leg must not be overwritten by a green kNN spot check."""
+    bench = _bench()
+    assert bench.run_failed({"dbscan_config3": False, "parity_spot_check": True})
+    assert bench.run_failed({"dbscan_config3": True, "parity_spot_check": False})
+    assert not bench.run_failed({"dbscan_config3": True, "parity_spot_check": True})
+    assert not bench.run_failed({})
+    # and the main body folds its checks through that function only
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert "failed = not ok" not in src.split("def dbscan_config3_leg")[0]

@@ -552,3 +552,49 @@ def test_rarely_taken_union_paths():
             assert all(expect in ln and ln.rstrip().endswith("union launches 1") for ln in lines), r.stdout
         else:
             assert all("union launches 2" in ln for ln in lines), r.stdout
+
+
+def _nested_clumps(rng, clumps, min_pts, eps):
+    """Isolated clumps of fewer than minPts + 3 points whose offsets from the clump's centre shrink geometrically (the radix
+    tree over a clump is a chain: a group five and more levels below the clump's node) and point in every direction, with
+    half extents between 0.30 and 0.56 eps -- from the middle, where one point sits, the WHOLE clump is within eps while the
+    clump's box has a diagonal above eps (no tight node).  scripts/db_twice_probe.py: the round-3 library gets 116 of
+    98 335 core flags wrong on this generator at minPts = 33 (none with one-sided clumps, none at minPts <= 16)."""
+    out = []
+    for c in rng.uniform(0.05, 0.95, (clumps, 3)):
+        m = int(rng.integers(max(3, min_pts // 2), min_pts + 3))
+        h = eps * rng.uniform(0.30, 0.56)
+        j = rng.integers(0, 9, (m, 1))
+        pts = c + rng.choice([-1.0, 1.0], (m, 3)) * h * (0.5 ** j) * rng.uniform(0.7, 1.0, (m, 3))
+        pts[0] = c
+        out.append(pts)
+    return np.concatenate(out).astype(np.float32)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("min_pts", [8, 16, 33, 64])
+def test_core_count_never_counts_a_subtree_twice(min_pts, monkeypatch):
+    """a point whose group cannot decide counts in the subtree four levels above its group first and then
+    over the rest of the tree, stepping over that subtree -- but an ANCESTOR of the subtree that lies inside the eps-sphere
+    used to be added whole, subtree included (6 + 7 = 13 >= minPts 10 for a point with 8 neighbours).  It takes minPts > 6,
+    small unbalanced clumps of an extent between eps and 2 eps, and a point near the middle: none of the other suite cases.
+    Core flags, counts and labels against the spec, with the walk to the group from the block paths and from the root.
+    (minPts = 33 uses the very set on which the round-3 library fails.)"""
+    from owlraytracing_amd.trueknn import TrueKNN
+    rng = np.random.default_rng(7 * min_pts + len("two_sided"))
+    eps = float(np.float32(0.004))
+    xyz = _nested_clumps(rng, 20000 if min_pts <= 33 else 8000, min_pts, eps)
+    ref = oracle.dbscan(xyz, eps, min_pts)
+    assert 0 < ref["core"].sum() < len(xyz)  # both kinds of clumps are there
+    eng = TrueKNN()
+    eng.build(xyz)
+    for paths in ("1", "0"):
+        monkeypatch.setenv("TKNN_DB_PATHS", paths)
+        got = eng.dbscan(eps, min_pts)
+        wrong = np.flatnonzero(got["core"].cpu().numpy().astype(bool) != ref["core"].astype(bool))
+        assert len(wrong) == 0, (paths, len(wrong), wrong[:5], ref["counts"][wrong[:5]])
+        assert np.array_equal(got["labels"].cpu().numpy(), ref["labels"]), paths
+        counted = eng.dbscan(eps, min_pts, want_counts=True)
+        assert np.array_equal(counted["counts"].cpu().numpy(), ref["counts"]), paths
+    monkeypatch.delenv("TKNN_DB_PATHS", raising=False)
+    eng.close()
