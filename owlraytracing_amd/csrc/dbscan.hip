@@ -28,6 +28,9 @@
 
 #include <hipcub/hipcub.hpp>
 
+#include <algorithm>
+#include <vector>
+
 #include <cstring>
 
 #ifndef TKNN_DIAG_BUILD
@@ -70,6 +73,7 @@ struct DbArgs {
   const int32_t *split_owner;  // Lbvh::split_owner_device()
   int32_t *uni;       // per internal node
   int32_t *uni_leaf;  // per sorted slot, written for the listed groups that are single points only
+  int32_t *pk_diag;  // diagnostic library, TKNN_DB_DIAG & 512: per packet of the timed pass: ticks, extent (1e-6), rounds, settles
   unsigned long long *diag_out;  // diagnostic library, TKNN_DB_DIAG & 512: the group-union kernel's wave time by part ([0] loads [1] tests [2] settles [3] pushes [4] packet set-up, s_memtime ticks) and [5] rounds [6] settles [7] packets
   int diag;  // TKNN_DB_DIAG, diagnostic library only (results are wrong when set): 1 = no probes, 2 = no unions between groups, 4 = none inside groups, 8 = walk lengths on stderr, 16 = report a stack overflow (the result is right: the call falls back), 32 = probes by scanning only (the result is right)
 };
@@ -360,14 +364,26 @@ __device__ __forceinline__ void db_core_body(const DbArgs &a, int32_t t, uint32_
   if (a.counts) a.counts[row] = cnt;
 }
 
-__global__ void __launch_bounds__(kDbBlock) db_core_kernel(DbArgs a) {
+// (`block_count`, or null: the workgroup's number of core slots, which the kernels behind this one place their lists by --
+// a launch of its own over all the flags otherwise, db_flag_count_kernel)
+__global__ void __launch_bounds__(kDbBlock) db_core_kernel(DbArgs a, int32_t *block_count) {
   __shared__ unsigned long long blk_stats[2];
+  __shared__ int32_t wave_count[kDbBlock / 64];
   if (threadIdx.x < 2) blk_stats[threadIdx.x] = 0ull;
   __syncthreads();
   uint32_t node_tests = 0, point_tests = 0;
   const int32_t t = blockIdx.x * kDbBlock + threadIdx.x;
   if (t < a.bvh.n) db_core_body(a, t, node_tests, point_tests);
-  db_add_stats(a.stats + 0, blk_stats, node_tests, point_tests);
+  if (block_count) {  // (a lane reads the flag it has just written)
+    const unsigned long long m = __ballot(t < a.bvh.n && a.core_sorted[t] != 0);
+    if ((threadIdx.x & 63) == 0) wave_count[threadIdx.x >> 6] = __popcll(m);
+  }
+  db_add_stats(a.stats + 0, blk_stats, node_tests, point_tests);  // (a barrier inside)
+  if (block_count && threadIdx.x == 0) {
+    int32_t total = 0;
+    for (int w = 0; w < kDbBlock / 64; w++) total += wave_count[w];
+    block_count[blockIdx.x] = total;
+  }
 }
 
 // next_core[s] = first core slot >= s (n if none): with rank[s] = number of core slots before s (an
@@ -1091,6 +1107,12 @@ __global__ void __launch_bounds__(kDbUnionBlock) __attribute__((amdgpu_waves_per
       DB_LAP(3);
     }
     if (__ballot(waiting > 0) != 0ull) settle();
+    if (timing && lane == 0 && a.pk_diag) {
+      float ext = 0.f;
+      for (int c = 0; c < 3; c++) ext = fmaxf(ext, fmaxf(u_hi[0][c], u_hi[kDbBoxes - 1][c]) - fminf(u_lo[0][c], u_lo[kDbBoxes - 1][c]));
+      int32_t *d = a.pk_diag + packet * 4;
+      d[0] = (int32_t)(__builtin_amdgcn_s_memtime() - packet_t0), d[1] = (int32_t)(ext * 1e6f), d[2] = (int32_t)(tm[5] - pk_rounds0), d[3] = (int32_t)(tm[6] - pk_settles0);
+    }
     if (timing && lane == 0) {  // the longest packet, and how many take more than twice / four times 2^20 ticks
       const unsigned long long el = __builtin_amdgcn_s_memtime() - packet_t0;
       atomicMax(&a.diag_out[12], el);
@@ -1248,8 +1270,12 @@ __global__ void __launch_bounds__(kDbBlock) db_border_walk_kernel(DbArgs a, cons
 // Labels: core points take their cluster's number (and every point's core flag goes to its row); the listed points take the
 // smallest number among the core neighbours db_border_walk_kernel has left them (or walk now).  ONE launch: the first
 // `walk_blocks` workgroups serve the list (grid-stride), the rest stream -- two scattered stores per point.
+// `by_slot` (or null): the labels stay BY SLOT -- a core slot's number (>= 0; four consecutive slots one 16-byte store), a
+// listed slot's -1 (noise) or -3 - label (border) -- and db_rows_from_slots_kernel carries them to the caller's rows through the
+// tree's inverse permutation with coalesced stores.  The scatter wrote a partial sector per point and array: rocprofv3 counted
+// 648 MB written for 50 MB of output at BASELINE config 3.
 __global__ void __launch_bounds__(kDbBlock) db_label_kernel(DbArgs a, const int32_t *pending, const unsigned long long *n_pending, int walk_blocks,
-                                                            const int32_t *lists, int per, long long capacity) {
+                                                            const int32_t *lists, int per, long long capacity, int32_t *by_slot) {
   __shared__ unsigned long long blk_stats[2];
   if (threadIdx.x < 2) blk_stats[threadIdx.x] = 0ull;
   __syncthreads();
@@ -1281,11 +1307,22 @@ __global__ void __launch_bounds__(kDbBlock) db_label_kernel(DbArgs a, const int3
     for (int k = 0; k < kDbPer; k++) first_row[k] = a.min_row[core[k] ? root[k] : 0];
 #pragma unroll
     for (int k = 0; k < kDbPer; k++) number[k] = a.rank[core[k] ? first_row[k] : 0];
+    if (by_slot) {
+      // (a slot that is not core belongs to the list part of this launch: not touched here)
+      if (t0 + kDbPer <= n && core[0] && core[1] && core[2] && core[3]) {
+        *reinterpret_cast<int4 *>(by_slot + t0) = make_int4(number[0], number[1], number[2], number[3]);
+      } else {
 #pragma unroll
-    for (int k = 0; k < kDbPer; k++) {
-      if (!in[k]) continue;
-      if (a.core) a.core[row[k]] = core[k];
-      if (core[k]) a.labels[row[k]] = number[k];
+        for (int k = 0; k < kDbPer; k++)
+          if (in[k] && core[k]) by_slot[t0 + k] = number[k];
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < kDbPer; k++) {
+        if (!in[k]) continue;
+        if (a.core) a.core[row[k]] = core[k];
+        if (core[k]) a.labels[row[k]] = number[k];
+      }
     }
   } else {
     const long long total = (long long)*n_pending;
@@ -1304,10 +1341,38 @@ __global__ void __launch_bounds__(kDbBlock) db_label_kernel(DbArgs a, const int3
         const LbvhPoint q = a.bvh.points[t];
         for_each_core_group(a, q, -1, [](int32_t) { return false; }, take, node_tests, point_tests);
       }
-      a.labels[a.bvh.prim_id[t]] = first_row < 0 ? -1 : a.rank[first_row];
+      const int32_t label = first_row < 0 ? -1 : a.rank[first_row];
+      if (by_slot)
+        by_slot[t] = label < 0 ? -1 : -3 - label;
+      else
+        a.labels[a.bvh.prim_id[t]] = label;
     }
   }
   db_add_stats(a.stats + 4, blk_stats, node_tests, point_tests);
+}
+// rows <- slots: four consecutive ROWS per thread; their slots come from the tree's inverse permutation (one 16-byte load), the
+// slots' words are four scattered 4-byte reads of an array the launch before has just written (40 MB at 10 M points: it sits
+// in the 256 MB of cache in front of the memory), the rows' labels and core flags leave as one 16-byte and one 4-byte store
+__global__ void __launch_bounds__(kDbBlock) db_rows_from_slots_kernel(DbArgs a, const int32_t *row_slot, const int32_t *by_slot) {
+  const int32_t n = a.bvh.n;
+  const long long r0 = ((long long)blockIdx.x * kDbBlock + threadIdx.x) * kDbPer;
+  if (r0 >= n) return;
+  int32_t v[kDbPer];
+  if (r0 + kDbPer <= n) {
+    const int4 s4 = *reinterpret_cast<const int4 *>(row_slot + r0);
+    v[0] = by_slot[s4.x], v[1] = by_slot[s4.y], v[2] = by_slot[s4.z], v[3] = by_slot[s4.w];
+    int32_t lab[kDbPer];
+#pragma unroll
+    for (int k = 0; k < kDbPer; k++) lab[k] = v[k] >= -1 ? v[k] : -3 - v[k];
+    *reinterpret_cast<int4 *>(a.labels + r0) = make_int4(lab[0], lab[1], lab[2], lab[3]);
+    if (a.core) *reinterpret_cast<uchar4 *>(a.core + r0) = make_uchar4(v[0] >= 0, v[1] >= 0, v[2] >= 0, v[3] >= 0);
+  } else {
+    for (long long r = r0; r < n; r++) {
+      const int32_t w = by_slot[row_slot[r]];
+      a.labels[r] = w >= -1 ? w : -3 - w;
+      if (a.core) a.core[r] = w >= 0;
+    }
+  }
 }
 
 // tknnDbscanAssign: the caller has decided the label of every core point (>= 0; < 0: not core); a
@@ -1478,7 +1543,7 @@ int64_t Engine::dbscan_noise(float eps, int min_pts, uint8_t *d_noise, hipStream
   void *scan_tmp = ws + need;
   const unsigned blocks = (unsigned)((n + kDbBlock - 1) / kDbBlock), blocks1 = (unsigned)((n + 1 + kDbBlock - 1) / kDbBlock);
   OWLMI_HIP(hipMemsetAsync(counters_, 0, (kCounters + kDbStripes * 8) * sizeof(unsigned long long), s));
-  hipLaunchKernelGGL(db_core_kernel, dim3(blocks), dim3(kDbBlock), 0, s, a);
+  hipLaunchKernelGGL(db_core_kernel, dim3(blocks), dim3(kDbBlock), 0, s, a, (int32_t *)nullptr);
   {
     int32_t *pos = a.rank;
     OWLMI_HIP(hipcub::DeviceScan::ExclusiveSum(scan_tmp, scan_bytes, DbFlagIter(a.core_sorted, DbFlagOf()), core_rank, (int)n, s));
@@ -1497,7 +1562,9 @@ void Engine::dbscan(float eps, int min_pts, int32_t *d_labels, uint8_t *d_core, 
   const int64_t n = bvh_.size();
   // scratch: core flags per slot, parent, root flags, ranks, next_core (+ two sentinels), smallest rows
   const size_t min_row_at = ((size_t)n * 17 + 8 + 15) / 16 * 16;
-  const size_t need = (min_row_at + (size_t)n * 16 + ((size_t)n / kDbBlock + 2) * 8 + 255) / 256 * 256;  // ... the list of the slots that are not core, their core neighbours
+  const size_t block_places_bytes = (((size_t)n / kDbBlock + 2) * 8 + 15) / 16 * 16;
+  const size_t max_packets = (size_t)n / 64 + 1;  // of db_group_union_kernel (their diagnostic records: the diagnostic library only)
+  const size_t need = (min_row_at + (size_t)n * 16 + block_places_bytes + (TKNN_DIAG_BUILD ? max_packets * 16 : 0) + 255) / 256 * 256;  // ... the list of the slots that are not core, their core neighbours
   size_t scan_bytes = 0;
   OWLMI_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, (int32_t *)nullptr, (int32_t *)nullptr, (int)n, s));
   {
@@ -1564,14 +1631,14 @@ void Engine::dbscan(float eps, int min_pts, int32_t *d_labels, uint8_t *d_core, 
     // caller's row from this kernel cost a partial sector per point (rocprofv3: 426 MB written for 10 M points)
     DbArgs c = a;
     c.core = nullptr;
-    hipLaunchKernelGGL(db_core_kernel, dim3(blocks), dim3(kDbBlock), 0, s, c);
+    hipLaunchKernelGGL(db_core_kernel, dim3(blocks), dim3(kDbBlock), 0, s, c, block_places);
   }
   OWLMI_HIP(hipEventRecord(ev_c_, s));  // end of the core-flag traversal
   {
     // next_core: flags -> exclusive sum (rank of a slot among the core slots) -> slot of the r-th core
     // point -> first core slot at or after each slot.  is_root / rank are free until the unions are done.
     int32_t *pos = a.rank;
-    hipLaunchKernelGGL(db_flag_count_kernel, dim3(blocks), dim3(kDbBlock), 0, s, a, block_places);
+    if (core_label) hipLaunchKernelGGL(db_flag_count_kernel, dim3(blocks), dim3(kDbBlock), 0, s, a, block_places);  // (else: db_core_kernel has counted)
     OWLMI_HIP(hipcub::DeviceScan::ExclusiveSum(scan_tmp, scan_bytes, block_places, block_places + blocks, (int)blocks, s));
     hipLaunchKernelGGL(db_core_pos_blocks_kernel, dim3(blocks), dim3(kDbBlock), 0, s, a, block_places + blocks, pos, core_label ? (int32_t *)nullptr : not_core, counters_ + 19);
     hipLaunchKernelGGL(db_next_core_blocks_kernel, dim3(blocks), dim3(kDbBlock), 0, s, a, block_places + blocks, pos, next_core);
@@ -1645,6 +1712,10 @@ void Engine::dbscan(float eps, int min_pts, int32_t *d_labels, uint8_t *d_core, 
     // reach of a pass's box prefilter is derived from its near_hi2 (>= its square root, DbArgs), so that no pair whose
     // faces are between split * eps_wide and sqrt(near_hi2) apart along one axis falls between the passes
     // (reach = split * eps (1 + 1e-6) against near2 <= split^2 eps^2 (1 + 1e-5) left a 34-ulp window).
+    if (TKNN_DIAG_BUILD && (a.diag & 512)) {
+      a.pk_diag = (int32_t *)((char *)block_places + block_places_bytes);
+      OWLMI_HIP(hipMemsetAsync(a.pk_diag, 0, max_packets * 16, s));
+    }
     a.near_lo2 = -1.f;
     a.near_hi2 = split * split * a.eps_out2;
     a.reach = db_reach_of(a.near_hi2);
@@ -1682,8 +1753,15 @@ void Engine::dbscan(float eps, int min_pts, int32_t *d_labels, uint8_t *d_core, 
   OWLMI_HIP(hipMemcpyAsync(&last[1], is_root + (n - 1), 4, hipMemcpyDeviceToHost, s));
   OWLMI_HIP(hipEventRecord(ev_f_, s));
   if (side) OWLMI_HIP(hipStreamWaitEvent(s, ev_side_b_, 0));
+  // labels by slot first and a gather to the rows (default), or scattered straight to the rows (TKNN_DB_LABEL=scatter: A/B).
+  // The caller's arrays must allow 16-byte stores for the gather (hipMalloc'd ones do).
+  const char *label_env = getenv("TKNN_DB_LABEL");
+  const int32_t *row_slot = bvh_.row_slot_device();
+  const bool gather = row_slot && !(label_env && std::strcmp(label_env, "scatter") == 0) && ((uintptr_t)d_labels % 16 == 0) && (!d_core || (uintptr_t)d_core % 4 == 0);
+  int32_t *by_slot = gather ? is_root : nullptr;  // (the root flags have been summed: their place is free)
   hipLaunchKernelGGL(db_label_kernel, dim3(walk_grid + blocks_per), dim3(kDbBlock), 0, s, a, not_core, counters_ + 19, (int)walk_grid,
-                     side ? border_lists : (const int32_t *)nullptr, border_per, (long long)n);
+                     side ? border_lists : (const int32_t *)nullptr, border_per, (long long)n, by_slot);
+  if (gather) hipLaunchKernelGGL(db_rows_from_slots_kernel, dim3(blocks_per), dim3(kDbBlock), 0, s, a, row_slot, by_slot);
   OWLMI_HIP(hipGetLastError());
   OWLMI_HIP(hipEventRecord(e1, s));
   OWLMI_HIP(hipMemcpyAsync(h_counters_ + 8, counters_ + 8, sizeof(unsigned long long), hipMemcpyDeviceToHost, s));   // groups
@@ -1725,6 +1803,31 @@ void Engine::dbscan(float eps, int min_pts, int32_t *d_labels, uint8_t *d_core, 
     info->union_launches = union_launches;
     info->union_node_tests = (int64_t)h_counters_[2];
     info->groups = per_point ? 0 : (int64_t)h_counters_[8];
+    if ((a.diag & 512) && a.pk_diag) {
+      // what the packets of the timed pass took, and when the launch would end if the waves took them longest first
+      // (TKNN_DB_DUMP=<file>: four int32 per packet -- ticks, extent in 1e-6, rounds, settles -- for scripts/db_packet_stats.py)
+      const size_t np = ((size_t)h_counters_[8] + 63) / 64;
+      std::vector<int32_t> d(np * 4);
+      OWLMI_HIP(hipMemcpy(d.data(), a.pk_diag, np * 16, hipMemcpyDeviceToHost));
+      if (const char *dump = getenv("TKNN_DB_DUMP")) {
+        if (FILE *f = std::fopen(dump, "wb")) {
+          std::fwrite(d.data(), 16, np, f);
+          std::fclose(f);
+        }
+      }
+      std::vector<size_t> order(np);
+      for (size_t i = 0; i < np; i++) order[i] = i;
+      std::sort(order.begin(), order.end(), [&](size_t x, size_t y) { return d[x * 4] > d[y * 4]; });
+      double sum = 0;
+      for (size_t i = 0; i < np; i++) sum += d[i * 4];
+      const int machines = (int)db_union_resident_ * (kDbUnionBlock / 64);
+      std::vector<double> load(machines, 0.0);
+      for (size_t i = 0; i < np; i++) load[std::min_element(load.begin(), load.end()) - load.begin()] += d[order[i] * 4];
+      std::fprintf(stderr, "[dbscan] %zu packets, %d waves: sum %.3g ticks, mean per wave %.0f, longest packet %d; longest-first would end at %.0f ticks\n", np, machines, sum,
+                   sum / machines, np ? d[order[0] * 4] : 0, *std::max_element(load.begin(), load.end()));
+      for (int i = 0; i < 6 && (size_t)i < np; i++)
+        std::fprintf(stderr, "[dbscan]   packet %zu: %d ticks, extent %.4f, %d rounds, %d settles\n", order[i], d[order[i] * 4], d[order[i] * 4 + 1] * 1e-6, d[order[i] * 4 + 2], d[order[i] * 4 + 3]);
+    }
     if (a.diag & 512) {
       unsigned long long t[20];
       OWLMI_HIP(hipMemcpy(t, counters_ + 20, sizeof t, hipMemcpyDeviceToHost));
@@ -1804,7 +1907,7 @@ void Engine::dbscan_auto(float eps0, int min_pts, double max_noise, int max_roun
     a.eps_in2 = eps * eps * (1.0f - 1e-5f);
     a.eps_out2 = eps * eps * (1.0f + 1e-5f);
     OWLMI_HIP(hipMemsetAsync(counters_, 0, (kCounters + kDbStripes * 8) * sizeof(unsigned long long), s));
-    hipLaunchKernelGGL(db_core_kernel, dim3(blocks), dim3(kDbBlock), 0, s, a);
+    hipLaunchKernelGGL(db_core_kernel, dim3(blocks), dim3(kDbBlock), 0, s, a, (int32_t *)nullptr);
     {
       int32_t *pos = a.rank;
         OWLMI_HIP(hipcub::DeviceScan::ExclusiveSum(scan_tmp, scan_bytes, DbFlagIter(a.core_sorted, DbFlagOf()), core_rank, (int)n, s));

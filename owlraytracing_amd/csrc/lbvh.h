@@ -61,6 +61,8 @@ class Lbvh {
   // range holds the whole block (last word) and its four nearest ancestors, the farthest first (the root where the path is
   // shorter): a walk down to one of the block's slots can start there instead of at the root
   const int32_t *block_paths_device() const { return point_mode_ && n_ > 1 ? block_paths_ : nullptr; }
+  // point trees: row_slot[row] = the sorted slot of the caller's row `row` (the inverse of prim_id), n entries
+  const int32_t *row_slot_device() const { return point_mode_ && built_ ? reinterpret_cast<const int32_t *>(order_) : nullptr; }
   int64_t size() const { return n_; }
   bool built() const { return built_; }
   void clear() { built_ = false; }  // marks the tree unusable (a failed rebuild); memory stays reserved

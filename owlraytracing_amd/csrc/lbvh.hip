@@ -150,7 +150,8 @@ __global__ void __launch_bounds__(kBlock) gather_kernel(const float *__restrict_
                                                        LbvhBox *__restrict__ sorted_boxes,
                                                        int32_t *__restrict__ prim_id,
                                                        const int32_t *__restrict__ ids,
-                                                       int32_t *__restrict__ nan_count) {
+                                                       int32_t *__restrict__ nan_count,
+                                                       int32_t *__restrict__ row_slot) {
   int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   if (i >= n) {
     // sentinels fill the last leaf block and one whole block after it (the team kernel's "no
@@ -165,6 +166,9 @@ __global__ void __launch_bounds__(kBlock) gather_kernel(const float *__restrict_
   }
   uint32_t src = order[i];
   prim_id[i] = (int32_t)src;
+  // the inverse of prim_id (point trees): a result that lives by sorted slot reaches the caller's rows by a GATHER with
+  // coalesced stores instead of a scatter of partial sectors (RT-DBSCAN's labels); lives in the sort's input buffer
+  if (row_slot) row_slot[src] = (int32_t)i;
   if (POINTS) {
     LbvhPoint p;
     p.x = xyz[3 * (int64_t)src];
@@ -515,7 +519,7 @@ void Lbvh::build_from_points(const float *d_xyz, int64_t n, hipStream_t stream, 
   OWLMI_HIP(hipMemsetAsync(nan_count(), 0, sizeof(int32_t), stream));
   sort_and_tree(stream);
   hipLaunchKernelGGL(gather_kernel<true>, dim3(blocks_for(n + 2 * LBVH_BLOCK)), dim3(kBlock), 0, stream, d_xyz,
-                     (const LbvhBox *)nullptr, n, order_alt_, points_, (LbvhBox *)nullptr, prim_id_, d_ids, nan_count());
+                     (const LbvhBox *)nullptr, n, order_alt_, points_, (LbvhBox *)nullptr, prim_id_, d_ids, nan_count(), (int32_t *)order_);
   OWLMI_HIP(hipGetLastError());
   fit(stream);
   build_wide(stream);
@@ -542,7 +546,7 @@ void Lbvh::build_from_boxes(const LbvhBox *d_boxes, int64_t n, hipStream_t strea
   OWLMI_HIP(hipMemsetAsync(nan_count(), 0, sizeof(int32_t), stream));
   sort_and_tree(stream);
   hipLaunchKernelGGL(gather_kernel<false>, dim3(blocks_for(n)), dim3(kBlock), 0, stream,
-                     (const float *)nullptr, d_boxes, n, order_alt_, (LbvhPoint *)nullptr, boxes_, prim_id_, (const int32_t *)nullptr, nan_count());
+                     (const float *)nullptr, d_boxes, n, order_alt_, (LbvhPoint *)nullptr, boxes_, prim_id_, (const int32_t *)nullptr, nan_count(), (int32_t *)nullptr);
   OWLMI_HIP(hipGetLastError());
   fit(stream);
   built_ = true;
@@ -551,7 +555,7 @@ void Lbvh::build_from_boxes(const LbvhBox *d_boxes, int64_t n, hipStream_t strea
 void Lbvh::refit_boxes(const LbvhBox *d_boxes, hipStream_t stream) {
   if (!built_ || point_mode_) throw HipError{"Lbvh::refit_boxes: no box tree to refit"};
   hipLaunchKernelGGL(gather_kernel<false>, dim3(blocks_for(n_)), dim3(kBlock), 0, stream,
-                     (const float *)nullptr, d_boxes, n_, order_alt_, (LbvhPoint *)nullptr, boxes_, prim_id_, (const int32_t *)nullptr, nan_count());
+                     (const float *)nullptr, d_boxes, n_, order_alt_, (LbvhPoint *)nullptr, boxes_, prim_id_, (const int32_t *)nullptr, nan_count(), (int32_t *)nullptr);
   OWLMI_HIP(hipGetLastError());
   fit(stream);
 }
