@@ -56,10 +56,14 @@ enum {
   TKNN_E_HIP = -2,      /* a HIP call failed; no device, out of memory, launch failure           */
   TKNN_E_STATE = -3,    /* call order: solve before build, ...                                   */
   TKNN_E_ROUNDS = -4,   /* max_rounds reached with unfinished queries (reference: endless loop)  */
-  TKNN_E_UNSUPPORTED = -5 /* k larger than the register-resident list of this build (TKNN_MAX_K) */
+  TKNN_E_UNSUPPORTED = -5 /* k above TKNN_MAX_K; a kernel asked for by name that does not serve this k  */
 };
 
-#define TKNN_MAX_K 64
+/* The reference takes any k from its command line (samples/s01-trueknn/hostCode.cpp:111) and keeps the lists in global
+ * memory (deviceCode.cu:77-134).  Here k <= 64 is served from registers (TKNN_KERNEL_LANE / _WAVE / _TEAM); 64 < k <=
+ * TKNN_MAX_K by the team walk with the lists in memory (TKNN_KERNEL_AUTO or _TEAM). */
+#define TKNN_MAX_K 1024
+#define TKNN_MAX_K_REGISTERS 64
 
 /* which traversal kernel tknnSolve uses */
 enum {

@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("OWL_MI355X_LIB") or os.path.join(_HERE, "libowl_mi355x.so")  # override: diagnostic builds
 
 KERNEL_AUTO, KERNEL_LANE, KERNEL_WAVE, KERNEL_TEAM = 0, 1, 2, 3
-MAX_K = 64
+MAX_K = 1024  # include/owlknn.h TKNN_MAX_K (k <= 64: register lists; above: the team walk with the lists in memory)
 
 
 class TknnError(RuntimeError):

@@ -530,6 +530,29 @@ __global__ void __launch_bounds__(256) unfinished_mask_kernel(const int32_t *lev
 }
 
 void Engine::solve(const SolveArgs &sa, int kernel, tknnSolveInfo *info, hipStream_t s) {
+  if (bigk_supports(sa.k)) {
+    // 64 < k <= TKNN_MAX_K: the team walk with the lists in memory, rows final (three-word keys: no tie pass)
+    if (kernel != TKNN_KERNEL_AUTO && kernel != TKNN_KERNEL_TEAM)
+      throw ArgError{TKNN_E_UNSUPPORTED, "the lane and wave kernels keep their lists in registers: k <= 64 (k up to TKNN_MAX_K: TKNN_KERNEL_AUTO or TKNN_KERNEL_TEAM)"};
+    if (sa.phase != 0) {
+      if (sa.phase == 3) {
+        if (!sa.d_levels) throw ArgError{TKNN_E_ARG, "tknnSolveEx: phase 3 (unfinished queries only) needs the d_levels of the call that left them"};
+        const int64_t n = bvh_.size();
+        hipLaunchKernelGGL(unfinished_mask_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, sa.d_levels, bvh_.view().prim_id, n, boundary_);
+        OWLMI_HIP(hipGetLastError());
+        boundary_valid_ = false;
+      } else if (!boundary_valid_) {
+        throw ArgError{TKNN_E_STATE, "tknnSolveEx: phase 1 / 2 need a tknnHaloSelect count pass since the last build (it marks the boundary queries)"};
+      }
+    }
+    struct HaloOffBig {
+      bool &flag;
+      explicit HaloOffBig(bool &f, bool on) : flag(f) { flag = on; }
+      ~HaloOffBig() { flag = false; }
+    } halo_off_big(ignore_halo_, sa.phase == 1);
+    solve_bigk(sa, info, s);
+    return;
+  }
   if (kernel == TKNN_KERNEL_TEAM && !team_kernel_supports(sa.k))
     throw ArgError{TKNN_E_UNSUPPORTED, "the team kernels hold up to four neighbours per lane of a 16-lane team: k <= 64"};
   if (kernel == TKNN_KERNEL_AUTO) {
@@ -774,7 +797,7 @@ int tknnRepairExact(tknnEngine e, int k, float start_radius, const int32_t *d_le
   }
   return guarded_on(e, [&] {
     if (!e->impl.built()) throw owlmi::ArgError{TKNN_E_STATE, "tknnRepairExact: call tknnBuild first"};
-    if (k <= 0 || k > TKNN_MAX_K) throw owlmi::ArgError{TKNN_E_ARG, "tknnRepairExact: k out of range"};
+    if (k <= 0 || k > TKNN_MAX_K_REGISTERS) throw owlmi::ArgError{TKNN_E_ARG, "tknnRepairExact: k out of range (1 .. 64: the repair pass keeps its lists in registers)"};
     if (!(start_radius > 0.f) || !std::isfinite(start_radius))
       throw owlmi::ArgError{TKNN_E_ARG, "tknnRepairExact: start_radius must be the one the rows were solved with"};
     const int64_t n = e->impl.repair_exact(k, start_radius, d_levels, d_idx, d_dist, (hipStream_t)stream);

@@ -78,6 +78,9 @@ class Engine {
   // trueknn_team.hip; returns false if a packet needed more leaf blocks than the kernel can name
   bool solve_team(const SolveArgs &sa, tknnSolveInfo *info, hipStream_t s);
   static bool team_kernel_supports(int k);
+  // trueknn_team.hip: 64 < k <= TKNN_MAX_K, the lists in memory (bigk_walk_kernel)
+  static bool bigk_supports(int k);
+  void solve_bigk(const SolveArgs &sa, tknnSolveInfo *info, hipStream_t s);
   // trueknn_team.hip: redo the rows flagged in tie_ with the reference's order of exact-distance ties
   void fix_ties(const SolveArgs &sa, tknnSolveInfo *info, hipStream_t s);
   void launch_tie_fix(const SolveArgs &sa, const int32_t *slots, int32_t nslots, int blocks, hipStream_t s,

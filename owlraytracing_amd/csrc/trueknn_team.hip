@@ -47,14 +47,18 @@ namespace owlmi {
 namespace {
 
 constexpr int kTeamBlock = 64;      // one wave per workgroup: LDS, not the block shape, limits residency
-constexpr int kMaxBlocks = 256;     // leaf blocks one packet may need per level (slot fits a byte)
+// leaf blocks one packet may need per level.  A per-query list names them by byte slots: 256 -- except with four list
+// registers per lane (k > 32), where the lists of the last level outgrow that (10 M uniform points at k = 64: 36 % of the queries
+// were handed to the team walk, two thirds of the solve): 512, the ninth bit of a slot in a word of its own
+// (96 bits per query)
+constexpr int max_blocks(int nreg) { return nreg == 4 ? 512 : 256; }
 #ifndef TKNN_MAX_PER_QUERY
 #define TKNN_MAX_PER_QUERY 72  // (k <= 16)
 #endif
 // leaf blocks one query may need per level: k <= 16 (one list register per lane) 72 -- lists of the benchmark run to 60 --,
-// larger k 96 (a third of the queries of 10 M uniform points need more than 72 at k = 32 and would be handed over)
+// k <= 32 96 (a third of the queries of 10 M uniform points need more than 72 at k = 32 and would be handed over), k > 32 124
 #ifndef TKNN_MAX_PER_QUERY_4
-#define TKNN_MAX_PER_QUERY_4 96  // (k > 32)
+#define TKNN_MAX_PER_QUERY_4 124  // (k > 32; round 4: with 512 blocks per packet the queries' own lists were what handed over)
 #endif
 constexpr int max_per_query(int nreg) { return nreg == 1 ? TKNN_MAX_PER_QUERY : (nreg == 4 ? TKNN_MAX_PER_QUERY_4 : 96); }
 #ifndef TKNN_MERGE_AT
@@ -74,7 +78,6 @@ constexpr int kMaxStep = 2;          // radius levels one gather may serve (the 
 // The pyramid stack is live only during the gather, the counts and the query list only during the
 // passes, so they share one region.  Every KB counts: LDS, not registers, limits residency.
 constexpr int kLdsQrec = 64 * kQrecStride * 4;
-constexpr int kLdsBlk = kMaxBlocks * 4;
 constexpr int kLdsCnt = 64 * 2 * 4;  // per query: candidates at the inner level, at the outer level | self << 31
 constexpr int kLdsList = 64 * 4 + 16;  // + the bucket-presence word of the list builder
 constexpr int kLdsStack = kTeamStack * 4;
@@ -89,18 +92,24 @@ constexpr int kCandCap = kCandCapacity;
 template <int NREG>
 struct TeamLayout {
   static constexpr int kMaxPerQuery = max_per_query(NREG);
+  static constexpr int kMaxBlocks = max_blocks(NREG);
+  static constexpr int kLdsBlk = kMaxBlocks * 4;
   static constexpr int kLdsMask = 64 * kMaxPerQuery;  // per-query lists of block slots (bytes)
+  static constexpr int kHiWords = kMaxBlocks > 256 ? (kMaxPerQuery + 31) / 32 : 0;  // per query: the slots' ninth bits
+  static constexpr int kLdsHi = 64 * kHiWords * 4;
   // per team: the block entries of the query it serves, resolved and in visit order (+ 4: a pass
   // prefetches one group of four past the end of a list rounded up to whole groups)
   static constexpr int kEntStride = kMaxPerQuery + 4;
   static constexpr int kLdsEnt = 4 * kEntStride * 4;
   static constexpr int kLdsCand = 4 * kCandCap * 8;
   static constexpr int kOffMask = kLdsQrec + kLdsBlk;
-  static constexpr int kOffShared = kOffMask + kLdsMask;
+  static constexpr int kOffHi = kOffMask + kLdsMask;
+  static constexpr int kOffShared = kOffHi + kLdsHi;
   static constexpr int kOffEnt = kOffShared + kLdsSharedPadded;
   static constexpr int kOffCand = kOffEnt + kLdsEnt;
   static constexpr int kTeamLds = kOffCand + kLdsCand;
   static_assert(kEntStride % 4 == 0 && kOffEnt % 16 == 0, "entry lists must be 16-byte aligned");
+  static_assert(kLdsMask % 4 == 0, "the ninth bits are words");
   static_assert(kMaxPerQuery <= 124 && kMaxPerQuery / 4 < 32, "list-length buckets of the pass lists are one bit each of a 32-bit word");
 };
 
@@ -410,6 +419,7 @@ struct TeamLds {
   float *qrec;        // [64][kQrecStride]
   int32_t *blk;       // [kMaxBlocks] block entries of the packet (bit 31: halo tree)
   uint8_t *qblk;      // [64][kMaxPerQuery] per-query slots into blk[]
+  uint32_t *qhi;      // [64][kHiWords] (k > 32) bit p of a query's words: the ninth bit of the slot at position p of its list
   uint32_t *qcnt;     // [64][2] out: candidates in the inner box, in the outer box | self << 31
   int32_t *qlist;     // compact list of the queries this pass serves
   int32_t *ent;       // [4][kEntStride] per team: resolved block entries of its query, in visit order
@@ -515,7 +525,9 @@ __device__ __forceinline__ void team_pass(const TeamArgs &a, const TeamLds &L, i
       int lp = list_pos(pos);
       if (n_near && lp >= n_near) lp = kMaxPerQuery - 1 - (lp - n_near);  // the back part, filled downwards
       const int at = min(max(lp, 0), kMaxPerQuery - 1);
-      int32_t e = L.blk[mine[at]];
+      int slot_at = mine[at];
+      if (TeamLayout<NREG>::kHiWords) slot_at |= (int)((L.qhi[qi * TeamLayout<NREG>::kHiWords + (at >> 5)] >> (at & 31)) & 1u) << 8;
+      int32_t e = L.blk[slot_at];
       if (TKNN_DIAG_BUILD && (a.diag & 64)) e = L.blk[mine[0]];  // every visit reads one and the same block: what do cache misses cost?
       return resolve_entry<HALO>(pos <= last ? e : nan_block);
     };
@@ -784,6 +796,8 @@ __global__ void __launch_bounds__(kTeamBlock) __attribute__((amdgpu_waves_per_eu
   float *qrec = (float *)base;
   int32_t *blk = (int32_t *)(base + kLdsQrec);
   uint8_t *qblk = (uint8_t *)(base + Lay::kOffMask);  // [query][kMaxPerQuery] slots into blk[]
+  uint32_t *qhi = (uint32_t *)(base + Lay::kOffHi);    // [query][kHiWords] their ninth bits (k > 32)
+  constexpr int kMaxBlocks = Lay::kMaxBlocks;
   uint32_t *qcnt = (uint32_t *)(base + Lay::kOffShared);
   int32_t *qlist = (int32_t *)(base + Lay::kOffShared + kLdsCnt);
   int32_t *stack = (int32_t *)(base + Lay::kOffShared);  // shares the counts / query list region
@@ -854,6 +868,7 @@ __global__ void __launch_bounds__(kTeamBlock) __attribute__((amdgpu_waves_per_eu
     L.qrec = qrec;
     L.blk = blk;
     L.qblk = qblk;
+    L.qhi = qhi;
     L.qcnt = qcnt;
     L.qlist = qlist;
     L.ent = ent;
@@ -993,6 +1008,10 @@ __global__ void __launch_bounds__(kTeamBlock) __attribute__((amdgpu_waves_per_eu
       my_own_pos = 0;
       int cur = 0;  // lane = query: blocks in the front part of my list | blocks in its back part << 16
       uint8_t *my_list = qblk + lane * kMaxPerQuery;
+      if (Lay::kHiWords) {
+#pragma unroll
+        for (int w = 0; w < Lay::kHiWords; w++) qhi[lane * Lay::kHiWords + w] = 0u;  // (my own words: no lane but mine writes them)
+      }
       int nb = 0, scanned = 0;
       for (int tree = 0; tree < 2 && !too_big; tree++) {
         const LbvhWideView &wv = a.wide[tree];
@@ -1095,7 +1114,9 @@ __global__ void __launch_bounds__(kTeamBlock) __attribute__((amdgpu_waves_per_eu
                 // that outgrows its slots keeps writing inside them (clamped): the packet walks again or is handed over.
                 const bool inner = gap <= reach_step;
                 const int at = inner ? (cur & 0xffff) : kMaxPerQuery - 1 - (cur >> 16);
-                my_list[min(max(at, 0), kMaxPerQuery - 1)] = (uint8_t)nb;  // (v_med3_i32)
+                const int at_c = min(max(at, 0), kMaxPerQuery - 1);  // (v_med3_i32)
+                my_list[at_c] = (uint8_t)nb;
+                if (Lay::kHiWords && nb >= 256) qhi[lane * Lay::kHiWords + (at_c >> 5)] |= 1u << (at_c & 31);
                 cur += inner ? 1 : 0x10000;
               }
               nb++;
@@ -1823,9 +1844,436 @@ __global__ void __launch_bounds__(kTeamBlock) tie_fix_kernel(TeamArgs a, const i
   if (lane == 0 && fsum) atomicAdd(&a.counters[kTieCounter + 2], fsum);
 }
 
+
+// ---- k > 64: the list in memory -----------------------------------------------------------------------------------------
+// The reference keeps every query's k-list in global memory and takes any k from its command line (hostCode.cpp:111,
+// deviceCode.cu:77-134).  The kernels above hold up to 64 entries in registers.  Larger lists live in memory, sixteen keys
+// to a CHUNK (lane j of the team reads and writes entry 16 c + j of chunk c: one coalesced 256-byte access, and always the
+// lane's own words), per team that is resident on the device, not per query: a query's list is built anew at every radius
+// level, as in team_walk_kernel, whose walk of the pyramid this kernel shares -- one query per team, its sixteen lanes the
+// child boxes of a wide node or the points of a leaf block.  Candidates wait in the team's LDS buffer and are merged a sorted
+// row of sixteen at a time (t_merge_rows with the registers in memory): the row goes to the first chunk whose largest distance
+// is not below the row's smallest (the chunks' maxima sit in LDS), meets it mirrored -- the sixteen smallest of both stay, the
+// sixteen largest travel on to the next chunk -- until what travels is empty.
+// Keys carry THREE words, (distance, level at which the neighbour first was a candidate, index): the reference's order of
+// bit-identical distances (section 1 of DESIGN.md; tie_fix_kernel's key), so rows come out final and no tie pass follows.
+struct BigKey {
+  uint32_t d, l, i, pad;
+};
+constexpr int kBigMaxChunks = TKNN_MAX_K / 16;
+static_assert(TKNN_MAX_K % 16 == 0 && kBigMaxChunks <= 64, "chunk maxima: 64 words of LDS per team");
+
+__device__ __forceinline__ bool t_less3(uint32_t ad, uint32_t al, uint32_t ai, uint32_t bd, uint32_t bl, uint32_t bi) {
+  const uint64_t ah = ((uint64_t)ad << 32) | al, bh = ((uint64_t)bd << 32) | bl;
+  return (ah < bh) | ((ah == bh) & (ai < bi));
+}
+// one compare-exchange of three-word keys with the lane whose key is (pd, pl, pi): the lower lane keeps the smaller key
+__device__ __forceinline__ void t_exchange3(uint32_t &kd, uint32_t &kl, uint32_t &ki, uint32_t pd, uint32_t pl, uint32_t pi, bool upper) {
+  const bool take = t_less3(pd, pl, pi, kd, kl, ki) != upper;
+  kd = take ? pd : kd;
+  kl = take ? pl : kl;
+  ki = take ? pi : ki;
+}
+#define T_EX3(CTRL, UP) t_exchange3(kd, kl, ki, t_dpp<CTRL>(kd), t_dpp<CTRL>(kl), t_dpp<CTRL>(ki), UP)
+__device__ __forceinline__ void t_sort16_3(uint32_t &kd, uint32_t &kl, uint32_t &ki, int tl) {
+  const bool up1 = (tl & 1) != 0, up2 = (tl & 2) != 0, up4 = (tl & 4) != 0, up8 = (tl & 8) != 0;
+  T_EX3(0xb1, up1);
+  T_EX3(0x1b, up2);
+  T_EX3(0xb1, up1);
+  T_EX3(0x141, up4);
+  T_EX3(0x4e, up2);
+  T_EX3(0xb1, up1);
+  T_EX3(0x140, up8);
+  t_exchange3(kd, kl, ki, t_xor4(kd), t_xor4(kl), t_xor4(ki), up4);
+  T_EX3(0x4e, up2);
+  T_EX3(0xb1, up1);
+}
+__device__ __forceinline__ void t_clean16_3(uint32_t &kd, uint32_t &kl, uint32_t &ki, int tl) {
+  const bool up1 = (tl & 1) != 0, up2 = (tl & 2) != 0, up4 = (tl & 4) != 0, up8 = (tl & 8) != 0;
+  T_EX3(0x128, up8);
+  t_exchange3(kd, kl, ki, t_xor4(kd), t_xor4(kl), t_xor4(ki), up4);
+  T_EX3(0x4e, up2);
+  T_EX3(0xb1, up1);
+}
+#undef T_EX3
+
+template <bool HALO>
+__global__ void __launch_bounds__(kTeamBlock) bigk_walk_kernel(TeamArgs a, BigKey *lists, int chunks) {
+  __shared__ int32_t stack_mem[4 * kWalkStack];
+  __shared__ WalkLevel levels[2][LBVH_WIDE_LEVELS];
+  __shared__ BigKey cand_mem[4 * kCandCapacity];     // per team: candidates waiting to be merged, (squared distance, first level, index)
+  __shared__ uint32_t cmax_mem[4 * kBigMaxChunks];   // per team and chunk of its list: the largest distance in it (bits)
+  const int lane = threadIdx.x & 63, team = lane >> 4, tl = lane & 15;
+  int32_t *stack = stack_mem + team * kWalkStack;
+  BigKey *my_cand = cand_mem + team * kCandCapacity;
+  uint32_t *my_cmax = cmax_mem + team * kBigMaxChunks;
+  BigKey *my_list = lists + ((size_t)blockIdx.x * 4 + (size_t)team) * (size_t)chunks * 16;
+  if (lane < 2 * LBVH_WIDE_LEVELS) {
+    const int t = lane / LBVH_WIDE_LEVELS, l = lane % LBVH_WIDE_LEVELS;
+    levels[t][l].boxes = a.wide[t].level[l];
+    levels[t][l].count = a.wide[t].count[l];
+  }
+  t_wave_sync();
+  const int32_t n = a.bvh.n;
+  const int kc = (a.k - 1) >> 4;  // the chunk of the k-th entry
+  unsigned long long isect_sum = 0, levels_sum = 0, node_tests = 0, point_tests = 0;
+  unsigned int unfinished = 0, failed = 0;
+  int max_level = 0;
+  for (;;) {
+    int base = 0;
+    if (lane == 0) base = (int)atomicAdd(&a.counters[0], 4ull);
+    base = __builtin_amdgcn_readfirstlane(base);
+    if (base >= n) break;
+    const int32_t slot = min(base + team, n - 1);
+    bool has_q = base + team < n;
+    if (has_q && a.skip && (int32_t)a.skip[slot] == a.skip_is) has_q = false;  // (tknnSolveOptions.phase: not a query of this call)
+    const LbvhPoint q = a.bvh.points[slot];
+    const int32_t row = a.bvh.prim_id[slot];
+    int level = 0;
+    int64_t isect = 0;
+    const float q_r0 = a.start_radii ? a.start_radii[row] : a.start_radius;
+    float r = q_r0;
+    bool active = has_q;
+    // A level only COUNTS (deviceCode.cu:74) as long as the query is unlikely to finish at it -- its box grows eightfold per
+    // level, so: fewer than k / 5 others at the level before, and in the first levels the scene's mean density (a.first_step)
+    // -- and keeps no list; a level that counts k others after all is walked once more, with the list.  (Every level with its
+    // list: 10 M uniform points at k = 65 took three times the k = 64 solve.)
+    uint32_t prev_others = 0;
+    bool again = false;  // this level has counted k others without a list
+    while (__ballot(active) != 0ull) {  // one radius level for every team that is still at work
+      const bool select_on = again || level >= a.first_step || prev_others * 5u >= (uint32_t)a.k;
+      const unsigned long long select_m = __ballot(select_on);
+      const float mg = (fmaxf(fmaxf(fabsf(q.x), fabsf(q.y)), fabsf(q.z)) + 2.0f * r) * 4.76837158203125e-07f;  // 2^-21
+      const float in_below = r - mg, in_upto = r + mg;
+      const float rl = r + 2.0f * mg, rs = r - 2.0f * mg;
+      uint32_t part = 0;       // my lane's share of the candidate count of this level
+      uint32_t n_list = 0;     // keys in my team's list (the same in its lanes)
+      uint32_t kth_bits = 0x7f7fffffu;  // distance of the list's k-th entry (FLT_MAX: not that many yet)
+      // (a squared distance that has overflowed is no neighbour: the reference's strict `<` against its initial FLT_MAX,
+      // hostCode.cpp:41, deviceCode.cu:116)
+      float tau2 = 3.402823466e+38f;
+      bool overflow = false;
+      uint32_t fill_n = 0;
+      // key word between distance and index: the level at which the candidate was first one (the box test is monotone in r)
+      auto first_level = [&](const LbvhPoint &p) -> uint32_t {
+        float rr = q_r0;
+        for (int l = 0; l < level; l++) {
+          if (knn_in_box(p.x, p.y, p.z, rr, q.x, q.y, q.z)) return (uint32_t)l;
+          rr = rr * 2.0f;
+        }
+        return (uint32_t)level;
+      };
+      auto merge_buffer = [&]() {
+        t_wave_sync();
+#pragma unroll 1
+        for (int rw = 0; rw < kCandCapacity / 16; rw++) {
+          if (rw > 0 && __ballot(fill_n > 16u * (uint32_t)rw) == 0ull) break;
+          const uint32_t at = 16u * (uint32_t)rw + (uint32_t)tl;
+          const bool have = at < fill_n;
+          BigKey c = {0u, 0u, 0u, 0u};
+          if (have) c = my_cand[at];
+          const float dist = knn_sqrt(__uint_as_float(c.d));
+          uint32_t kd = have ? __float_as_uint(dist) : 0x7f7fffffu, kl = have ? c.l : 0u, ki = have ? c.i : 0u;  // the empty key past the end
+          t_sort16_3(kd, kl, ki, tl);
+          const uint32_t in_row = fill_n > 16u * (uint32_t)rw ? min(fill_n - 16u * (uint32_t)rw, 16u) : 0u;
+          const uint32_t row_min = t_lane_read(kd, team << 4);
+          const int nch = (int)((n_list + 15u) >> 4);  // chunks that hold keys
+          // the first chunk a key of the row can get into: the chunks whose largest distance is below the row's smallest stay
+          uint32_t below = 0;
+          for (int j = tl; j < nch; j += 16) below += my_cmax[j] < row_min ? 1u : 0u;
+          const int j0 = (int)t_team_sum(below);
+          const int jend = min(nch, chunks - 1);  // ... and the last: the first chunk without keys, if the list has room for one
+          bool live = in_row > 0u;                // what travels still holds keys
+          int j_first = live ? j0 : 0x7fffffff;
+#pragma unroll
+          for (int off = 32; off > 0; off >>= 1) j_first = min(j_first, __shfl_xor(j_first, off));
+          for (int j = j_first; __ballot(live && j <= jend) != 0ull; j++) {
+            const bool on = live && j >= j0 && j <= jend;
+            BigKey e = {0x7f7fffffu, 0u, 0u, 0u};
+            if (on && j < nch) e = my_list[(size_t)j * 16 + tl];
+            const uint32_t od = t_dpp<0x140>(kd), ol = t_dpp<0x140>(kl), oi = t_dpp<0x140>(ki);  // the row's key 15 - tl
+            const bool take = t_less3(od, ol, oi, e.d, e.l, e.i);
+            uint32_t hd = take ? e.d : od, hl = take ? e.l : ol, hi_i = take ? e.i : oi;  // the larger of the pair: travels on
+            uint32_t ld = take ? od : e.d, ll = take ? ol : e.l, li = take ? oi : e.i;    // the smaller: stays in this chunk
+            t_clean16_3(ld, ll, li, tl);
+            t_clean16_3(hd, hl, hi_i, tl);
+            const uint32_t kth_here = t_lane_read(ld, (team << 4) + ((a.k - 1) & 15));
+            if (on) {
+              my_list[(size_t)j * 16 + tl] = BigKey{ld, ll, li, 0u};
+              if (tl == 15) my_cmax[j] = ld;
+              if (j == kc) kth_bits = kth_here;
+              kd = hd, kl = hl, ki = hi_i;
+            }
+            const bool more = ((uint32_t)(__ballot(kd != 0x7f7fffffu) >> (team * 16)) & 0xffffu) != 0u;
+            if (on) live = more && j < nch;  // (a chunk that held no key takes all that travels)
+          }
+          n_list = min((uint32_t)chunks * 16u, n_list + in_row);
+          t_wave_sync();  // (the chunk maxima are read by the next row's lanes)
+        }
+        fill_n = 0;
+        tau2 = fminf(3.402823466e+38f, knn_gate_from_worst(__uint_as_float(kth_bits)));
+      };
+      for (int tree = 0; tree < (HALO ? 2 : 1); tree++) {
+        const LbvhWideView &wv = a.wide[tree];
+        const LbvhView &tv = tree == 0 ? a.bvh : a.halo;
+        if (tv.n <= 0 || wv.levels <= 0) continue;
+        const int32_t clean_end = tv.n - (tv.nan_count ? *tv.nan_count : 0);  // NaN points sort last
+        int sp = 0;
+        if (active) {
+          if (tl == 0) stack[0] = (wv.levels << 26) | 0;  // virtual root above the top level
+          sp = 1;
+        }
+        t_wave_sync();
+        while (__ballot(sp > 0) != 0ull) {
+          const bool work = sp > 0;
+          const int32_t e = work ? stack[sp - 1] : (1 << 26);
+          if (work) sp--;
+          const int lvl = (e >> 26) - 1;  // level of the children
+          const int32_t first_child = (e & 0x3ffffff) * 64;
+          const WalkLevel wl = levels[tree][lvl];
+          const int32_t nchild = lvl == wv.levels - 1 ? (first_child == 0 ? wl.count : 0) : wl.count;
+          LbvhBox bx4[4];
+#pragma unroll
+          for (int chunk = 0; chunk < 4; chunk++) {
+            const int32_t c = first_child + 16 * chunk + tl;
+            bx4[chunk] = LbvhBox{{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
+            if (work && c < nchild) bx4[chunk] = wl.boxes[c];
+          }
+#pragma unroll 1
+          for (int chunk = 0; chunk < 4; chunk++) {  // (not unrolled: the merge below is large; the box by selects, not by an index)
+            const int32_t c = first_child + 16 * chunk + tl;
+            const bool valid = work && c < nchild;
+            LbvhBox bx = bx4[0];
+#pragma unroll
+            for (int u = 1; u < 4; u++)
+              if (chunk == u) bx = bx4[u];
+            const bool ov = valid & (bx.lo[0] <= q.x + rl) & (bx.hi[0] >= q.x - rl) & (bx.lo[1] <= q.y + rl) &
+                            (bx.hi[1] >= q.y - rl) & (bx.lo[2] <= q.z + rl) & (bx.hi[2] >= q.z - rl);
+            node_tests += valid ? 1u : 0u;
+            bool counted = false;  // inside the certain part of my box and beyond the gate: count, do not walk (team_walk_kernel)
+            if (ov) {
+              const bool inside = (bx.lo[0] >= q.x - rs) & (bx.hi[0] <= q.x + rs) & (bx.lo[1] >= q.y - rs) &
+                                  (bx.hi[1] <= q.y + rs) & (bx.lo[2] >= q.z - rs) & (bx.hi[2] <= q.z + rs);
+              if (inside) {
+                const float gx = fmaxf(fmaxf(bx.lo[0] - q.x, q.x - bx.hi[0]), 0.f), gy = fmaxf(fmaxf(bx.lo[1] - q.y, q.y - bx.hi[1]), 0.f),
+                            gz = fmaxf(fmaxf(bx.lo[2] - q.z, q.z - bx.hi[2]), 0.f);
+                const float m2 = (gx * gx + gy * gy) + gz * gz;
+                const int64_t span = (int64_t)LBVH_BLOCK << (6 * lvl);  // points under one child of this level
+                const int64_t first = (int64_t)c * span;
+                if (m2 * 0.999995f > tau2 && first + span <= (int64_t)clean_end) {
+                  part += (uint32_t)span;
+                  counted = true;
+                }
+              }
+            }
+            const bool keep = ov && !counted;
+            const uint32_t keep_mine = (uint32_t)(__ballot(keep) >> (team * 16)) & 0xffffu;
+            if (lvl > 0) {
+              if (sp + __popc(keep_mine) > kWalkStack) {
+                overflow = true;
+              } else {
+                if (keep) stack[sp + __popc(keep_mine & ((1u << tl) - 1u))] = (lvl << 26) | c;
+                sp += __popc(keep_mine);
+              }
+            } else {
+              uint32_t todo = keep_mine;
+              while (__ballot(todo != 0u) != 0ull) {
+                const bool has_b = todo != 0u;
+                const int32_t b = first_child + 16 * chunk + (has_b ? __ffs((int)todo) - 1 : 0);
+                todo &= todo - 1u;
+                LbvhPoint p = {__uint_as_float(0x7fc00000u), 0.f, 0.f, -1};
+                if (has_b) p = tv.points[(int64_t)b * LBVH_BLOCK + tl];
+                point_tests += has_b ? 1u : 0u;
+                const float dx = p.x - q.x, dy = p.y - q.y, dz = p.z - q.z;
+                const float t = has_b ? fmaxf(fmaxf(fabsf(dx), fabsf(dy)), fabsf(dz)) : __uint_as_float(0x7fc00000u);
+                unsigned long long in_m = __ballot(t <= in_below);
+                const unsigned long long maybe_m = __ballot(t <= in_upto) & ~in_m;
+                if (maybe_m) in_m |= maybe_m & __ballot(knn_in_box(p.x, p.y, p.z, r, q.x, q.y, q.z));
+                part = t_count(part, in_m);
+                const float d2 = t_dist2(dx, dy, dz);
+                const unsigned long long pm = in_m & __ballot(p.id != q.id) & __ballot(d2 <= tau2) & select_m;
+                if (pm) {
+                  const uint32_t mine16 = (uint32_t)(pm >> (team << 4)) & 0xffffu;  // my team's lanes with a candidate
+                  if ((mine16 >> tl) & 1u)
+                    my_cand[fill_n + __popc(mine16 & ((1u << tl) - 1u))] = BigKey{__float_as_uint(d2), first_level(p), (uint32_t)p.id, 0u};
+                  fill_n += __popc(mine16);
+                  if (__ballot(fill_n >= 16u) != 0ull) merge_buffer();
+                }
+              }
+            }
+          }
+          t_wave_sync();
+        }
+      }
+      if (__ballot(fill_n > 0u) != 0ull) merge_buffer();
+      // ---- the level's outcome, per team ----
+      const uint32_t cnt = t_team_sum(part);
+      const uint32_t others = cnt ? cnt - 1u : 0u;  // a query lies in its own box
+      const bool fin = active && !overflow && others >= (uint32_t)a.k;
+      if (active && overflow) {  // (cannot happen: 63 siblings wait on each of at most six levels; reported, never wrong)
+        failed += tl == 0 ? 1u : 0u;
+        active = false;
+      } else if (active && fin && !select_on) {
+        again = true;  // the same level once more, with its list
+      } else if (active) {
+        again = false;
+        prev_others = others;
+        isect += cnt;
+        levels_sum += tl == 0 ? 1ull : 0ull;
+        if (fin) {
+          for (int j = 0; j <= kc; j++) {
+            const int en = 16 * j + tl;
+            if (en >= a.k) continue;
+            const BigKey ky = my_list[(size_t)j * 16 + tl];
+            const int64_t o = (int64_t)row * a.k + en;
+            const int32_t prim = (ky.d == 0x7f7fffffu && ky.i == 0u) ? -1 : (int32_t)ky.i;
+            const float d = __uint_as_float(ky.d);
+            if (a.out_idx) a.out_idx[o] = prim;
+            if (a.out_dist) a.out_dist[o] = d;
+            if (a.out_fb) {
+              tknnNeigh ev;
+              ev.ind = prim;
+              ev.dist = d;
+              ev.numNeighbors = en == 0 ? 0 : a.k;
+              ev.pad_ = 0;
+              ev.intersections = en == 0 ? isect : 0;
+              a.out_fb[o] = ev;
+            }
+          }
+          if (tl == 0) {
+            if (a.out_isect) a.out_isect[row] = isect;
+            if (a.out_level) a.out_level[row] = level;
+            a.done[slot] = 1;
+            isect_sum += (unsigned long long)isect;
+          }
+          max_level = max(max_level, level + 1);
+          active = false;
+        } else {
+          level++;
+          r = r * 2.0f;  // hostCode.cpp:321
+          if (level >= a.max_rounds) {
+            if (tl == 0) {
+              a.isect_sorted[slot] = isect;
+              a.next_level[slot] = level;
+              unfinished++;
+            }
+            max_level = max(max_level, level);
+            active = false;
+          }
+        }
+      }
+    }
+  }
+  const unsigned long long isum = t_wave_sum(isect_sum), lsum = t_wave_sum(levels_sum), nt = t_wave_sum(node_tests),
+                           pt = t_wave_sum(point_tests) * LBVH_BLOCK / 16, usum = t_wave_sum((unsigned long long)unfinished),
+                           fsum = t_wave_sum((unsigned long long)failed);
+  const int ml = (int)t_wave_max((float)max_level);
+  if (lane == 0) {
+    atomicMax(&a.counters[1], (unsigned long long)ml);
+    atomicAdd(&a.counters[2], nt);
+    atomicAdd(&a.counters[3], pt);
+    atomicAdd(&a.counters[4], isum);
+    atomicAdd(&a.counters[6], lsum);
+    if (usum) atomicAdd(&a.counters[7], usum);
+    if (fsum) atomicAdd(&a.counters[8], fsum);
+  }
+}
+
 }  // namespace
 
 bool Engine::team_kernel_supports(int k) { return k >= 1 && k <= 64; }
+
+bool Engine::bigk_supports(int k) { return k > 64 && k <= TKNN_MAX_K; }
+
+// k > 64: every query through bigk_walk_kernel, one query per team, the k-lists in memory (one per resident team)
+void Engine::solve_bigk(const SolveArgs &sa, tknnSolveInfo *info, hipStream_t s) {
+  const int64_t n = bvh_.size();
+  TeamArgs a;
+  std::memset(&a, 0, sizeof a);
+  a.bvh = bvh_.view();
+  a.halo = halo_view();
+  a.wide[0] = bvh_.wide_view();
+  if (halo_count() > 0) a.wide[1] = halo_.wide_view();
+  a.start_radius = sa.start_radius;
+  a.start_radii = sa.d_start_radii;
+  a.k = sa.k;
+  a.max_rounds = sa.max_rounds;
+  a.allow_unfinished = sa.allow_unfinished ? 1 : 0;
+  // the first level that keeps a list whatever the level before has counted: where a box is expected to hold k / 2 others at the
+  // scene's mean density (a work estimate only; a per-query radius schedule has none: every level keeps its list)
+  a.first_step = sa.d_start_radii ? 0 : first_step_estimate(sa) - 1;
+  a.out_idx = sa.d_idx;
+  a.out_dist = sa.d_dist;
+  a.out_isect = sa.d_isect;
+  a.out_fb = sa.d_fb;
+  a.out_level = sa.d_levels;
+  a.done = done_;
+  a.tie = tie_;
+  a.tie_list = tie_list_;
+  a.skip = sa.phase ? boundary_ : nullptr;
+  a.skip_is = sa.phase == 1 ? 1 : 0;
+  a.isect_sorted = isect_sorted_;
+  a.next_level = next_level_;
+  a.counters = counters_;
+  const bool with_halo = halo_count() > 0;
+  hipDeviceProp_t prop;
+  OWLMI_HIP(hipGetDeviceProperties(&prop, device_));
+  int per_cu = 4;
+  const void *entry = with_halo ? (const void *)bigk_walk_kernel<true> : (const void *)bigk_walk_kernel<false>;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, entry, kTeamBlock, 0) != hipSuccess) per_cu = 4;
+  const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>((n + 3) / 4, (int64_t)prop.multiProcessorCount * std::max(1, per_cu)));
+  const int chunks = (sa.k + 15) / 16;
+  const size_t list_bytes = (size_t)blocks * 4 * (size_t)chunks * 16 * sizeof(BigKey);
+  if (list_bytes > wave_ws_bytes_) {
+    if (wave_ws_) (void)hipFree(wave_ws_);
+    wave_ws_ = nullptr;
+    wave_ws_bytes_ = 0;
+    OWLMI_HIP(hipMalloc(&wave_ws_, list_bytes));
+    wave_ws_bytes_ = list_bytes;
+  }
+  OWLMI_HIP(hipMemsetAsync(tie_, 0, (size_t)n, s));  // (three-word keys: no row is left to the tie pass)
+  OWLMI_HIP(hipMemsetAsync(counters_, 0, kCounters * sizeof(unsigned long long), s));
+  OWLMI_HIP(hipMemsetAsync(done_, 0, (size_t)n, s));
+  OWLMI_HIP(hipMemsetAsync(isect_sorted_, 0, (size_t)n * sizeof(int64_t), s));
+  OWLMI_HIP(hipMemsetAsync(next_level_, 0, (size_t)n * sizeof(int32_t), s));
+  if (sa.d_levels && sa.phase < 2) OWLMI_HIP(hipMemsetAsync(sa.d_levels, 0xff, (size_t)n * sizeof(int32_t), s));  // (phases 2, 3 complete an earlier call's rows)
+  OWLMI_HIP(hipEventRecord(ev_a_, s));
+  {
+    BigKey *lists = (BigKey *)wave_ws_;
+    int ch = chunks;
+    void *kargs[] = {(void *)&a, (void *)&lists, (void *)&ch};
+    OWLMI_HIP(hipLaunchKernel(entry, dim3(blocks), dim3(kTeamBlock), kargs, 0, s));
+  }
+  OWLMI_HIP(hipGetLastError());
+  OWLMI_HIP(hipEventRecord(ev_b_, s));
+  OWLMI_HIP(hipMemcpyAsync(h_counters_, counters_, 10 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+  OWLMI_HIP(hipStreamSynchronize(s));
+  float ms = 0;
+  OWLMI_HIP(hipEventElapsedTime(&ms, ev_a_, ev_b_));
+  if (h_counters_[8]) throw ArgError{TKNN_E_UNSUPPORTED, "k > 64: a query's walk outgrew its stack (a pyramid of more than six levels?)"};
+  tknnSolveInfo mine;
+  std::memset(&mine, 0, sizeof mine);
+  mine.rounds = (int)h_counters_[1];
+  mine.node_tests = (int64_t)h_counters_[2];
+  mine.point_tests = (int64_t)h_counters_[3];
+  mine.total_intersections = (int64_t)h_counters_[4];
+  mine.total_active_rounds = (int64_t)h_counters_[6];
+  mine.unfinished = (int64_t)h_counters_[7];
+  mine.solve_ms = ms;
+  mine.dominant_kernel_ms = ms;
+  mine.dominant_kernel_launches = 1;
+  mine.kernel_used = TKNN_KERNEL_TEAM;
+  mine.list_capacity = chunks * 16;
+  float radius = sa.start_radius;
+  for (int t = 1; t < mine.rounds; t++) radius *= 2;
+  mine.final_radius = radius;
+  if (mine.unfinished && !sa.allow_unfinished) throw RoundsExceeded{};
+  ties_early_ = true;  // nothing flagged, nothing to redo
+  early_tie_rows_ = early_tie_left_ = 0;
+  early_tie_ms_ = 0.f;
+  if (info) *info = mine;
+}
+
 
 void Engine::launch_tie_fix(const SolveArgs &sa, const int32_t *slots, int32_t nslots, int blocks, hipStream_t s, const int32_t *d_slot_count) {
   TeamArgs a;

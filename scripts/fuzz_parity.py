@@ -51,7 +51,8 @@ def main():
         n = int(10 ** rng.uniform(1.9, 5.2))
         name, xyz = make(rng, n)
         n = len(xyz)
-        k = int(rng.choice([1, 2, 3, 5, 8, 10, 16, 17, 24, 32, 33, 48, 64]))
+        k = int(rng.choice([1, 2, 3, 5, 8, 10, 16, 17, 24, 32, 33, 48, 64, 65, 80, 100, 160, 300]))
+        kernels = (_lib.KERNEL_TEAM, _lib.KERNEL_WAVE, _lib.KERNEL_LANE) if k <= 64 else (_lib.KERNEL_TEAM,)  # (k > 64: the lists in memory, team walk only)
         if n <= k + 1:
             continue
         ext = float(np.ptp(xyz, axis=0).max()) or 1.0
@@ -62,7 +63,7 @@ def main():
             print("skip %s n=%d k=%d r0=%g: %s" % (name, n, k, r0, e), flush=True)
             continue
         eng.build(xyz)
-        for kern in (_lib.KERNEL_TEAM, _lib.KERNEL_WAVE, _lib.KERNEL_LANE):
+        for kern in kernels:
             r = eng.solve(k, r0, kernel=kern)
             tag = "%s n=%d k=%d r0=%g kernel=%d" % (name, n, k, r0, kern)
             assert r["info"]["rounds"] == ref["rounds"], tag
@@ -82,7 +83,7 @@ def main():
                 sub = oracle.trueknn(xyz, k, r0, query_ids=own, max_rounds=64)
                 eng.build(xyz[own], own)
                 eng.set_halo(xyz[rest], rest)
-                for kern in (_lib.KERNEL_TEAM, _lib.KERNEL_WAVE, _lib.KERNEL_LANE):
+                for kern in kernels:
                     r = eng.solve(k, r0, kernel=kern)
                     tag = "halo %s n=%d own=%d k=%d r0=%g kernel=%d" % (name, n, len(own), k, r0, kern)
                     assert np.array_equal(r["intersections"].cpu().numpy(), sub["intersections"][own]), tag

@@ -46,6 +46,10 @@ def cases():
     yield "minimal_n6_k5", datasets.uniform3d(6, seed=10), 5, 0.05
     yield "taxi2d_n3000_k7", datasets.pad_to_3d(datasets.taxi_like2d(3000, components=16, seed=2)), 7, 0.001
     yield "k32_n2500", datasets.uniform3d(2500, seed=11), 32, 0.03
+    # k above the engine's register lists (the reference takes any k, hostCode.cpp:111): the team walk with the lists in memory
+    yield "k65_n1000", datasets.uniform3d(1000, seed=12), 65, 0.05
+    yield "k100_n800", datasets.gaussian_mixture3d(800, components=4, sigma=0.05, seed=13), 100, 0.02
+    yield "k256_n600", datasets.uniform3d(600, seed=14), 256, 0.1
     # satellites on the box faces of 40 anchors, +-2 ulps, coordinates from 1e-3 to 600
     yield "boundaryband_n3640_k7", datasets.boundary_band(40, 0.01, seed=4), 7, 0.01
     # exact-distance ties between candidates first seen in different rounds (persistent lists)

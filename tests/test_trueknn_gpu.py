@@ -27,9 +27,12 @@ def test_golden_vectors(golden, kernel):
     eng = _engine()
     eng.build(golden["xyz"])
     k = int(golden["k"])
-    if kernel == _lib.KERNEL_TEAM and k > 64:
-        with pytest.raises(_lib.TknnError):
+    if kernel != _lib.KERNEL_TEAM and k > 64:
+        # the lane and wave kernels keep their lists in registers (k <= 64); larger k: the team walk with the lists in memory
+        with pytest.raises(_lib.TknnError) as e:
             eng.solve(k, float(golden["start_radius"]), kernel=kernel)
+        assert e.value.code == -5  # TKNN_E_UNSUPPORTED
+        eng.close()
         return
     r = eng.solve(k, float(golden["start_radius"]), kernel=kernel, want_fb=True)
     # (the team kernel finishes packets whose candidate sets outgrow its lists with lane rounds or the
@@ -40,6 +43,10 @@ def test_golden_vectors(golden, kernel):
     # (crossroundties_*: exact distance ties between candidates of different rounds, which the replay --
     # and the engines' tie pass -- order by the round first seen, then by index)
     assert_rows_match(r["idx"].cpu().numpy(), r["dist"].cpu().numpy(), r["intersections"].cpu().numpy(), golden)
+    if k > 64:
+        assert r["info"]["list_capacity"] == (k + 15) // 16 * 16 and r["info"]["tie_rows"] == 0  # three-word keys: rows are final
+        auto = eng.solve(k, float(golden["start_radius"]))  # TKNN_KERNEL_AUTO takes the same path
+        assert np.array_equal(auto["idx"].cpu().numpy(), r["idx"].cpu().numpy())
     if golden["name"].startswith("crossroundties"):
         assert r["info"]["tie_rows"] > 0 and r["info"]["tie_rows_left"] == 0
     assert r["info"]["total_intersections"] == int(golden["intersections"].sum())
@@ -55,13 +62,19 @@ def test_golden_vectors(golden, kernel):
 @pytest.mark.parametrize("kernel", KERNELS, ids=KERNEL_IDS)
 @pytest.mark.parametrize("n,k,seed", [(100_000, 5, 0), (50_000, 10, 1), (30_000, 16, 2), (20_000, 3, 3),
                                       (30_000, 17, 4), (40_000, 24, 5), (25_000, 32, 6), (25_000, 33, 7), (20_000, 50, 8),
-                                      (20_000, 64, 9)])
+                                      (20_000, 64, 9), (12_000, 65, 10), (10_000, 100, 11), (6_000, 256, 12), (5_000, 1024, 13)])
 def test_against_oracle_uniform(kernel, n, k, seed):
     xyz = datasets.uniform3d(n, seed=seed)
     r0 = datasets.start_radius(n, k)
-    ref = oracle.trueknn(xyz, k, r0)
     eng = _engine()
     eng.build(xyz)
+    if k > 64 and kernel != _lib.KERNEL_TEAM:  # (k above the register lists: the team walk with the lists in memory only)
+        with pytest.raises(_lib.TknnError) as e:
+            eng.solve(k, r0, kernel=kernel)
+        assert e.value.code == -5
+        eng.close()
+        return
+    ref = oracle.trueknn(xyz, k, r0)
     r = eng.solve(k, r0, kernel=kernel)
     assert r["info"]["rounds"] == ref["rounds"]
     assert_rows_equal(r["idx"].cpu().numpy(), r["dist"].cpu().numpy(), ref["idx"], ref["dist"])
@@ -226,7 +239,7 @@ _TIE_SETS = {}
 
 @pytest.mark.parametrize("kernel", KERNELS, ids=KERNEL_IDS)
 @pytest.mark.parametrize("tail", [None, "walk", "lane"])
-@pytest.mark.parametrize("k", [1, 5, 16, 17, 32, 33, 64])
+@pytest.mark.parametrize("k", [1, 5, 16, 17, 32, 33, 64, 65, 100])
 def test_tie_heavy_sets_equal_the_replay(kernel, tail, k, monkeypatch):
     """Lattices with holes and coarsely quantised coordinates: almost every row has bit-identical
     distances inside it or at its end, many of them between candidates of different rounds.  k = 16,
@@ -234,6 +247,8 @@ def test_tie_heavy_sets_equal_the_replay(kernel, tail, k, monkeypatch):
     seen by what leaves the list, not by a spare entry)."""
     if tail and kernel != _lib.KERNEL_TEAM:
         pytest.skip("tails belong to the team kernel")
+    if k > 64 and (tail or kernel != _lib.KERNEL_TEAM):
+        pytest.skip("k > 64: the team walk with the lists in memory, no packet kernel, no tails")
     if tail:
         monkeypatch.setenv("TKNN_TEAM_TAIL", tail)
     if k not in _TIE_SETS:  # the replay of a set is shared by the kernels and tails
@@ -247,7 +262,10 @@ def test_tie_heavy_sets_equal_the_replay(kernel, tail, k, monkeypatch):
         r = eng.solve(k, r0, kernel=kernel)
         assert np.array_equal(r["intersections"].cpu().numpy(), ref["intersections"])
         assert_rows_equal(r["idx"].cpu().numpy(), r["dist"].cpu().numpy(), ref["idx"], ref["dist"])
-        assert r["info"]["tie_rows"] > 0 and r["info"]["tie_rows_left"] == 0
+        if k > 64:
+            assert r["info"]["tie_rows"] == 0  # (the lists order by (distance, first level, index) from the start)
+        else:
+            assert r["info"]["tie_rows"] > 0 and r["info"]["tie_rows_left"] == 0
         eng.close()
 
 
@@ -395,7 +413,7 @@ def test_argument_errors_are_reported_not_hidden():
     assert e.value.code == -3  # TKNN_E_STATE
     xyz = datasets.uniform3d(10, seed=0)
     eng.build(xyz)
-    for k, r0, code in ((10, 0.1, -1), (0, 0.1, -1), (3, 0.0, -1), (3, float("inf"), -1), (65, 0.1, -5)):
+    for k, r0, code in ((10, 0.1, -1), (0, 0.1, -1), (3, 0.0, -1), (3, float("inf"), -1), (65, 0.1, -1), (1025, 0.1, -5)):
         with pytest.raises(_lib.TknnError) as e:
             eng.solve(k, r0)
         assert e.value.code == code
