@@ -143,16 +143,133 @@ def copy_bandwidth(dev):
     return 2 * (1 << 28) * 4 / (best * 1e-3) / 1e9
 
 
+def sharded_trueknn_run(solver, dist, dev, backend, world, n_total, k, steps, warmup):
+    """One timed run of the Morton-tile driver over the counter-based uniform set of `n_total` points (all ranks call it):
+    load + tile + build (untimed), `warmup` solves, `steps` solves between barriers, the slowest rank's clock.  Returns what
+    the JSON line (or one of its sub-objects) carries: value, ms_per_step, per-rank records, the slowest rank's phase times."""
+    from owlraytracing_amd import datasets
+
+    r0 = datasets.start_radius(n_total, k)
+    solver.load_counter_based(n_total, seed=0)  # one-time: generate, Morton-tile, build own trees
+    n_local = len(solver.points)
+    for _ in range(warmup):
+        solver.solve(k, r0)
+    dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    infos = []
+    for _ in range(steps):
+        infos.append(solver.solve(k, r0))
+    torch.cuda.synchronize()
+    dist.barrier()
+    elapsed_own = time.perf_counter() - t0
+    t = torch.tensor([elapsed_own], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+    last = infos[-1]
+    # one record per rank (an imbalance -- tile sizes come from 1 024 samples per rank -- must be visible in the one line a
+    # hardware run leaves): points, halo rows, exchanges, this rank's own step time, and the per-phase wall times of two more,
+    # instrumented steps (a device synchronisation after every phase, so they are not part of the timed region)
+    names = ["select", "exchange", "halo_build", "solve", "reduce"]
+    mine = [float(n_local), float(last.get("halo_points", 0)), float(last.get("halo_exchanges", 0)), elapsed_own / steps * 1e3]
+    solver.profile = True
+    ph = [solver.solve(k, r0)["phase_ms"] for _ in range(2)]
+    solver.profile = False
+    mine += [float(np.mean([p_.get(nm, 0.0) for p_ in ph])) for nm in names]
+    mine.append(float(np.mean([i["dominant_kernel_ms"] for i in infos])))
+    v = torch.tensor(mine, dtype=torch.float64, device=dev if backend == "nccl" else "cpu")  # (gloo gathers host tensors only)
+    every = [torch.empty_like(v) for _ in range(world)]
+    dist.all_gather(every, v)
+    rows = [e.tolist() for e in every]
+    hp = torch.tensor([int(last.get("halo_points", 0))], dtype=torch.int64, device=dev)
+    dist.all_reduce(hp, op=dist.ReduceOp.SUM)
+    return {
+        "value": n_total * steps / elapsed,
+        "ms_per_step": elapsed / steps * 1e3,
+        "steps": steps,
+        "warmup": warmup,
+        "n_points_total": n_total,
+        "start_radius": r0,
+        "n_local": n_local,
+        "infos": infos,
+        "ranks": [{"rank": j, "points": int(r_[0]), "halo_points": int(r_[1]), "halo_exchanges": int(r_[2]), "ms_per_step_own_clock": r_[3],
+                   "phase_ms": {nm: r_[4 + i] for i, nm in enumerate(names)}, "kernel_ms": r_[4 + len(names)]} for j, r_ in enumerate(rows)],
+        "phase_ms": {nm: max(r_[4 + i] for r_ in rows) for i, nm in enumerate(names)},  # the slowest rank of each phase
+        "halo_points": int(hp.item()),
+        "halo_exchanges": int(last.get("halo_exchanges", 0)),
+    }
+
+
+def sharded_dbscan_records(solver, dist, dev, backend, world, eps32, min_pts, infos, n_local, ms_own):
+    """What a sharded RT-DBSCAN line carries beside its value (it had neither phases nor kernel times nor a
+    roofline): one record per rank -- points, halo, label rounds, its own step time, the phases of two more, instrumented
+    steps (set-up: halo selection + exchange + tree; the tile's clustering with its three traversal kernels' device times;
+    label propagation; numbering; border assignment) -- the slowest rank of each phase, and rank 0's per-kernel rooflines
+    (the tile's own + halo points: the set its engine clustered)."""
+    last = infos[-1]
+    solver.profile = True
+    prof = [solver.dbscan(eps32, min_pts)["info"] for _ in range(2)]
+    solver.profile = False
+    names = ["setup", "cluster", "propagate", "number", "assign"]
+    knames = ["core_ms", "union_ms", "label_ms", "solve_ms"]
+    eng = [p_.get("engine") or {} for p_ in prof]
+    mine = [float(n_local), float(last.get("halo_points", 0)), float(last.get("label_rounds", last.get("rounds", 0))), ms_own]
+    mine += [float(np.mean([p_.get("phase_ms", {}).get(nm, 0.0) for p_ in prof])) for nm in names]
+    mine += [float(np.mean([e_.get(nm, 0.0) for e_ in eng])) for nm in knames]
+    v = torch.tensor(mine, dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+    every = [torch.empty_like(v) for _ in range(world)]
+    dist.all_gather(every, v)
+    rows = [e.tolist() for e in every]
+    hp = torch.tensor([int(last.get("halo_points", 0))], dtype=torch.int64, device=dev)
+    dist.all_reduce(hp, op=dist.ReduceOp.SUM)
+    out = {
+        "ranks": [{"rank": j, "points": int(r_[0]), "halo_points": int(r_[1]), "label_rounds": int(r_[2]), "ms_per_step_own_clock": r_[3],
+                   "phase_ms": {nm: r_[4 + i] for i, nm in enumerate(names)},
+                   "kernel_ms": {nm: r_[4 + len(names) + i] for i, nm in enumerate(knames)}} for j, r_ in enumerate(rows)],
+        "phase_ms": {nm: max(r_[4 + i] for r_ in rows) for i, nm in enumerate(names)},
+        "halo_points": int(hp.item()),
+        "halo_exchanges": int(last.get("halo_exchanges", 1)),
+        "label_rounds": int(last.get("label_rounds", last.get("rounds", 0))),
+    }
+    if eng and eng[-1].get("groups") is not None and "union_node_tests" in eng[-1]:
+        kernels = dbscan_rooflines(eng[-1], eng, int(eng[-1].get("n_clustered", n_local)), min_pts)
+        dom = max(kernels, key=lambda nm: kernels[nm]["kernel_ms"] * kernels[nm]["launches_per_step"])
+        out["roofline"] = dict(kernels[dom])
+        out["roofline"]["kernels"] = kernels
+        out["roofline"]["of"] = "rank 0's tile and its 2-eps halo (%d points)" % int(eng[-1].get("n_clustered", n_local))
+    return out
+
+
+def exchange_label(backend):
+    """What carried the halo rows in THIS run (the line said "RCCL" whatever the backend)."""
+    return "RCCL (nccl backend) halo exchange" if backend == "nccl" else "%s-backend rehearsal: halo rows staged through the host, ranks may share a GPU" % backend
+
+
+def sub_object(run, world, k, what):
+    """A second workload of the same multi-rank run, as a sub-object of the JSON line (same clock rules as the headline)."""
+    return {"metric": "kNN queries/sec (%s pts, k=%d)" % (size_label(run["n_points_total"]), k), "value": run["value"], "unit": "queries/s",
+            "n_gpus": world, "steps": run["steps"], "warmup": run["warmup"], "ms_per_step": run["ms_per_step"], "scaling": what,
+            "n_points_total": run["n_points_total"], "start_radius": run["start_radius"], "ranks": run["ranks"], "phase_ms": run["phase_ms"],
+            "halo_points": run["halo_points"], "halo_exchanges": run["halo_exchanges"],
+            "kernel_ms_mean_over_ranks": float(np.mean([r_["kernel_ms"] for r_ in run["ranks"]]))}
+
+
+def size_label(n):
+    return "%dM" % (n // 1_000_000) if n % 1_000_000 == 0 else str(n)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", choices=("trueknn", "dbscan"), default="trueknn")
-    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
-                    help="weak: --points per GPU; strong: --points in all, cut into one Morton tile per GPU")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default=None,
+                    help="weak: --points per GPU; strong: --points in all, cut into one Morton tile per GPU.  Default with N > 1 and no "
+                         "--points: BASELINE's 10 M set cut into N tiles (strong) as the headline, N x 10 M (weak) and, at N = 8, the 100 M set "
+                         "of configs[3] as sub-objects of the line")
     # (not "--n": torch.distributed.run's own parser stumbles over script options that abbreviate its --nnodes / --nproc-per-node)
-    ap.add_argument("--points", dest="n", type=int, default=N_POINTS, help="points per GPU (weak) or in all (strong); default: BASELINE config 2")
+    ap.add_argument("--points", dest="n", type=int, default=None, help="points per GPU (weak) or in all (strong); default: BASELINE config 2's 10 M")
     ap.add_argument("--k", type=int, default=K)
     ap.add_argument("--eps", type=float, default=DB_EPS)
     ap.add_argument("--min-pts", type=int, default=DB_MINPTS)
@@ -185,10 +302,17 @@ def main():
     k = args.k
     sharded = world > 1 or args.sharded
     dbscan = args.workload == "dbscan"
-    n_total = args.n if (args.scaling == "strong" or not sharded) else args.n * world
+    # N > 1 without --scaling / --points: the headline is BASELINE's OWN set -- configs[1], 10 M points -- cut into N Morton tiles
+    # ("kNN queries/sec (10M pts, k=10) at 1/2/4/8 MI355X": strong scaling), with N x 10 M (weak) and, at N = 8, configs[3]
+    # (100 M points, strong) as sub-objects of the same line (the default used to time N x 10 M under the 10 M metric)
+    default_multi = sharded and not dbscan and args.scaling is None and args.n is None
+    scaling = args.scaling or ("strong" if default_multi else "weak")
+    n_arg = args.n if args.n is not None else N_POINTS
+    n_total = n_arg if (scaling == "strong" or not sharded) else n_arg * world
     eps32 = float(np.float32(args.eps))
     dist = None
     extra = {}
+    run = None
     if sharded:
         import torch.distributed as dist
 
@@ -205,17 +329,27 @@ def main():
             else:
                 dist.init_process_group(backend)
         solver = tkd.ShardedTrueKNN(dev, kernel=args.kernel)
-        if dbscan:
-            # every rank draws the whole mixture's slice it is given (the generator is sequential: slices of one stream)
-            lo, hi = n_total * rank // world, n_total * (rank + 1) // world
-            pts = datasets.gaussian_mixture3d(n_total, components=64, sigma=0.02, seed=1)[lo:hi]
-            solver.load_points(torch.from_numpy(pts), torch.arange(lo, hi, dtype=torch.int32))
-            step = lambda: solver.dbscan(eps32, args.min_pts)["info"]  # noqa: E731
-            r0 = None
-        else:
-            r0 = datasets.start_radius(n_total, k)
-            solver.load_counter_based(n_total, seed=0)  # one-time: generate, Morton-tile, build own trees
-            step = lambda: solver.solve(k, r0)  # noqa: E731
+    if sharded and not dbscan:
+        run = sharded_trueknn_run(solver, dist, dev, backend, world, n_total, k, args.steps, args.warmup)
+        r0, n_local, infos = run["start_radius"], run["n_local"], run["infos"]
+        elapsed = run["ms_per_step"] * args.steps / 1e3
+        for key in ("ranks", "phase_ms", "halo_points", "halo_exchanges"):
+            extra[key] = run[key]
+        if default_multi and world > 1:
+            few = max(1, min(args.steps, 5))
+            weak = sharded_trueknn_run(solver, dist, dev, backend, world, N_POINTS * world, k, few, 1)
+            extra["weak"] = sub_object(weak, world, k, "weak")
+            if world == 8:
+                c4 = sharded_trueknn_run(solver, dist, dev, backend, world, 100_000_000, k, few, 1)
+                extra["config4"] = sub_object(c4, world, k, "strong")
+                extra["config4"]["config"] = "BASELINE.json configs[3]: TrueKNN on 100M uniform 3-D points, k=10, Morton-tiled across 8 GPUs"
+    elif sharded:
+        # every rank draws the whole mixture's slice it is given (the generator is sequential: slices of one stream)
+        lo, hi = n_total * rank // world, n_total * (rank + 1) // world
+        pts = datasets.gaussian_mixture3d(n_total, components=64, sigma=0.02, seed=1)[lo:hi]
+        solver.load_points(torch.from_numpy(pts), torch.arange(lo, hi, dtype=torch.int32))
+        step = lambda: solver.dbscan(eps32, args.min_pts)["info"]  # noqa: E731
+        r0 = None
         n_local = len(solver.points)
     else:
         if dbscan:
@@ -242,61 +376,39 @@ def main():
                 out.update({kk: v for kk, v in r.items() if kk != "info"})
                 return r["info"]
 
-    for _ in range(args.warmup):
-        info = step()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    infos = []
-    for _ in range(args.steps):
-        infos.append(step())
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    elapsed_own = elapsed
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-        last = infos[-1]
-        # one record per rank (an imbalance -- tile sizes come from 1 024 samples per rank -- must be visible in the one line
-        # a hardware run leaves): points, halo rows, exchanges, this rank's own step time, and the per-phase wall times of
-        # two more, instrumented steps (a device synchronisation after every phase, so they are not part of the timed region)
-        names = ["select", "exchange", "halo_build", "solve", "reduce"]
-        mine = [float(n_local), float(last.get("halo_points", 0)), float(last.get("halo_exchanges", 1 if dbscan else 0)), elapsed_own / args.steps * 1e3]
-        if not dbscan:
-            solver.profile = True
-            ph = [solver.solve(k, r0)["phase_ms"] for _ in range(2)]
-            solver.profile = False
-            mine += [float(np.mean([p.get(nm, 0.0) for p in ph])) for nm in names]
-            mine.append(float(np.mean([i["dominant_kernel_ms"] for i in infos])))
-        v = torch.tensor(mine, dtype=torch.float64, device=dev if backend == "nccl" else "cpu")  # (gloo gathers host tensors only)
-        every = [torch.empty_like(v) for _ in range(world)]
-        dist.all_gather(every, v)
-        rows = [e.tolist() for e in every]
-        extra["ranks"] = [dict({"rank": j, "points": int(r_[0]), "halo_points": int(r_[1]), "halo_exchanges": int(r_[2]), "ms_per_step_own_clock": r_[3]},
-                               **({"phase_ms": {nm: r_[4 + i] for i, nm in enumerate(names)}, "kernel_ms": r_[4 + len(names)]} if not dbscan else {}))
-                          for j, r_ in enumerate(rows)]
-        if not dbscan:
-            extra["phase_ms"] = {nm: max(r_[4 + i] for r_ in rows) for i, nm in enumerate(names)}  # the slowest rank of each phase
-        hp = torch.tensor([int(last.get("halo_points", 0))], dtype=torch.int64, device=dev)
-        dist.all_reduce(hp, op=dist.ReduceOp.SUM)
-        extra["halo_points"] = int(hp.item())
-        extra["halo_exchanges"] = int(last.get("halo_exchanges", 1 if dbscan else 0))
-        if dbscan:
-            extra["label_rounds"] = int(last.get("label_rounds", last.get("rounds", 0)))
+    if run is None:
+        for _ in range(args.warmup):
+            info = step()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        infos = []
+        for _ in range(args.steps):
+            infos.append(step())
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        elapsed = time.perf_counter() - t0
+        elapsed_own = elapsed
+        if dist is not None:  # (sharded RT-DBSCAN)
+            t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+            extra.update(sharded_dbscan_records(solver, dist, dev, backend, world, eps32, args.min_pts, infos, n_local, elapsed_own / args.steps * 1e3))
 
     ms_per_step = elapsed / args.steps * 1e3
     value = n_total * args.steps / elapsed
     info = infos[-1]
-    tiles = "" if not sharded else "; %d Morton tiles, RCCL halo exchange" % world
+    tiles = "" if not sharded else "; %d Morton tiles, %s" % (world, exchange_label(backend))
     if dbscan:
         line = dbscan_line(args, info, infos, value, ms_per_step, n_total, n_local, world, sharded, eps32, tiles)
+        if sharded and "roofline" in extra:
+            line["roofline"] = extra.pop("roofline")
     else:
-        line = trueknn_line(args, info, infos, value, ms_per_step, n_total, n_local, world, sharded, r0, tiles)
-    line["scaling"] = args.scaling if sharded else "weak"
+        line = trueknn_line(args, info, infos, value, ms_per_step, n_total, n_local, world, sharded, r0, tiles, scaling)
+    line["scaling"] = scaling if sharded else "weak"
+    line["backend"] = backend if sharded else None
     line.update(extra)
     checks = {}  # named result checks of this run; ANY red one fails the run (run_failed)
     if not sharded:
@@ -364,7 +476,7 @@ def run_failed(checks):
     return any(not ok for ok in checks.values())
 
 
-def trueknn_line(args, info, infos, value, ms_per_step, n_total, n_local, world, sharded, r0, tiles):
+def trueknn_line(args, info, infos, value, ms_per_step, n_total, n_local, world, sharded, r0, tiles, scaling="weak"):
     k = args.k
     kern_ms = float(np.mean([i["dominant_kernel_ms"] for i in infos]))
     total_isect = int(info["total_intersections"])
@@ -375,7 +487,8 @@ def trueknn_line(args, info, infos, value, ms_per_step, n_total, n_local, world,
     kernel_name = {1: "lane_round_kernel", 2: "wave_packet_kernel", 3: "team_kernel"}.get(int(info["kernel_used"]), "?")
     rec, why_not = committed_profile(kernel_name, n_local, k)
     line = {
-        "metric": "kNN queries/sec (10M pts, k=10)",
+        # (the metric names the set that was timed: BASELINE's "10M pts, k=10" only when that is what ran)
+        "metric": "kNN queries/sec (%s pts, k=%d)" % (size_label(n_total), k),
         "value": value,
         "unit": "queries/s",
         "n_gpus": world,
@@ -390,10 +503,11 @@ def trueknn_line(args, info, infos, value, ms_per_step, n_total, n_local, world,
         "config": {
             "workload": "TrueKNN on %d uniform-random 3-D points%s (%s), k=%d, start radius 0.25*(k/n)^(1/3)=%.6g; "
                         "BASELINE.json configs[%d]%s" % (
-                            n_total if args.scaling == "strong" or not sharded else n_local,
-                            " in all" if args.scaling == "strong" and sharded else (" per GPU" if sharded else ""),
+                            n_total,
+                            " in all, cut into %d tiles" % world if sharded and scaling == "strong" else (" in all, %d per GPU" % (n_total // world) if sharded else ""),
                             "counter-based Philox(0), [0,1)^3" if sharded else "numpy default_rng(0), [0,1)^3", k, r0,
                             3 if n_total >= 100_000_000 and sharded else 1, tiles),
+            "ranks": world,
             "n_points_total": n_total,
             "k": k,
             "start_radius": r0,
@@ -454,7 +568,7 @@ def trueknn_line(args, info, infos, value, ms_per_step, n_total, n_local, world,
 
 def dbscan_line(args, info, infos, value, ms_per_step, n_total, n_local, world, sharded, eps32, tiles):
     line = {
-        "metric": "RT-DBSCAN points/sec (10M Gaussian-mixture pts, eps=0.01, minPts=4)",
+        "metric": "RT-DBSCAN points/sec (%s Gaussian-mixture pts, eps=%.6g, minPts=%d)" % (size_label(n_total), eps32, args.min_pts),
         "value": value,
         "unit": "points/s",
         "n_gpus": world,
@@ -477,9 +591,9 @@ def dbscan_line(args, info, infos, value, ms_per_step, n_total, n_local, world, 
         "clusters": int(info.get("clusters", -1)),
     }
     if sharded:
-        # the sharded driver reports clusters / rounds / halo only; the per-kernel figures are the tiles' own
+        # (main() replaces this with rank 0's per-kernel rooflines: sharded_dbscan_records)
         line["roofline"] = {"bound": "hbm", "kernel": "db_group_union_kernel", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                            "frac": None, "traffic": None, "note": "per-kernel counters are reported by the single-GPU run"}
+                            "frac": None, "traffic": None, "note": "no engine record of the tile's clustering in this run"}
         return line
     kernels = dbscan_rooflines(info, infos, n_local, args.min_pts)
     # the dominant traversal kernel of the call, by its own HIP-event time (all of them under "kernels")

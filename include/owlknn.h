@@ -240,6 +240,11 @@ TKNN_API int tknnDbscanAuto(tknnEngine e, float eps0, int min_pts, double max_no
 /* One growth round's question alone, for a caller that runs the loop itself (the sharded driver: the tiles' halos grow with
  * eps): d_noise[row] = 1 if the point would be labelled -1 by tknnDbscan(eps, min_pts) -- it is not core and has no core
  * point within eps --, 0 otherwise; no clusters are built.  *noise_count (may be NULL) = how many. */
+/* Sharded RT-DBSCAN (owlraytracing_amd/distributed.py): d_out[d_segment[i]] = min(d_out[d_segment[i]], d_value[i])
+ * over the n elements with d_segment[i] >= 0; d_out is preset by the caller.  The one per-point step of the label
+ * propagation over tiles: the smallest global id of every local cluster.  On the engine's device. */
+TKNN_API int tknnSegmentMin(tknnEngine e, const int32_t *d_segment, const int64_t *d_value, int64_t n, int64_t *d_out, void *stream);
+
 TKNN_API int tknnDbscanNoise(tknnEngine e, float eps, int min_pts, uint8_t *d_noise, int64_t *noise_count, void *stream);
 
 /* Test / debug export of the tree to host memory (any pointer may be NULL):

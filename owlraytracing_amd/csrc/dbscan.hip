@@ -1492,6 +1492,47 @@ __global__ void __launch_bounds__(kDbBlock) db_rows_kernel(DbArgs a, const uint8
 
 }  // namespace
 
+// tknnSegmentMin (sharded RT-DBSCAN, owlraytracing_amd/distributed.py): out[seg[i]] = min(out[seg[i]], val[i]) over the
+// elements with seg[i] >= 0 -- the smallest global id of every local cluster, the one per-point step of the label propagation
+// (everything after it works on clusters and halo rows).  Few segments and ten million elements is the hard case -- a
+// scatter-reduce queues its atomics on a few dozen addresses (two ranks, BASELINE config 3: 160 ms of a 174 ms step) --; as in
+// db_min_row the value only falls, so an element that reads a smaller or equal one is done, and a wave first settles the two
+// segments most of its lanes hold with one atomic each.
+__global__ void __launch_bounds__(kDbBlock) db_segment_min_kernel(const int32_t *seg, const long long *val, long long n, long long *out) {
+  const long long i = (long long)blockIdx.x * kDbBlock + threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  int32_t my_seg = -1;
+  long long my_val = 0x7fffffffffffffffll;
+  if (i < n) {
+    my_seg = seg[i];
+    if (my_seg >= 0) my_val = val[i];
+  }
+  bool pending = my_seg >= 0;
+  if (pending && __hip_atomic_load(out + my_seg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) <= my_val) pending = false;
+  for (int round = 0; round < 2; round++) {
+    const unsigned long long todo = __ballot(pending);
+    if (!todo) break;
+    const int j = __ffsll((long long)todo) - 1;
+    const int32_t s_j = __shfl(my_seg, j);
+    const bool same = pending && my_seg == s_j;
+    long long m = same ? my_val : 0x7fffffffffffffffll;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      const long long o = __shfl_xor(m, off);
+      m = o < m ? o : m;
+    }
+    if (lane == j) atomicMin(out + s_j, m);
+    pending = pending && !same;
+  }
+  if (pending) atomicMin(out + my_seg, my_val);
+}
+void db_segment_min(const int32_t *d_seg, const int64_t *d_val, int64_t n, int64_t *d_out, hipStream_t s) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(db_segment_min_kernel, dim3((unsigned)((n + kDbBlock - 1) / kDbBlock)), dim3(kDbBlock), 0, s, d_seg, (const long long *)d_val, (long long)n,
+                     (long long *)d_out);
+  OWLMI_HIP(hipGetLastError());
+}
+
 // the work counters of the launches so far: the stripes to the host (synchronises the stream), summed into h_counters_[0..7]
 void Engine::db_read_stats(hipStream_t s) {
   OWLMI_HIP(hipMemcpyAsync(h_counters_ + 16, counters_ + kCounters, kDbStripes * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));

@@ -864,6 +864,14 @@ int tknnDbscanNoise(tknnEngine e, float eps, int min_pts, uint8_t *d_noise, int6
   });
 }
 
+int tknnSegmentMin(tknnEngine e, const int32_t *d_segment, const int64_t *d_value, int64_t n, int64_t *d_out, void *stream) {
+  if (!e || n < 0 || (n > 0 && (!d_segment || !d_value || !d_out))) {
+    g_last_error = "tknnSegmentMin: engine, segments, values and the output are required";
+    return TKNN_E_ARG;
+  }
+  return guarded_on(e, [&] { owlmi::db_segment_min(d_segment, d_value, n, d_out, (hipStream_t)stream); });
+}
+
 int tknnExportTree(tknnEngine e, void *nodes, int32_t *rope_node, int32_t *rope_leaf, int32_t *prim_id,
                    void *stream) {
   if (!e) {

@@ -34,6 +34,9 @@ struct SolveArgs {
 // smallest register-list capacity instantiated for k, or -1
 int list_capacity_for(int k);
 
+// dbscan.hip: out[seg[i]] = min(out[seg[i]], val[i]) for seg[i] >= 0 (tknnSegmentMin)
+void db_segment_min(const int32_t *d_seg, const int64_t *d_val, int64_t n, int64_t *d_out, hipStream_t s);
+
 // test hook: the wave kernel's exact candidate thresholds for (q, r) pairs (trueknn_wave.hip)
 void debug_thresholds(const float *d_q, const float *d_r, int64_t n, float *d_lo, float *d_hi, hipStream_t s);
 

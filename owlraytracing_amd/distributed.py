@@ -491,19 +491,20 @@ class ShardedTrueKNN:
                 res["info"] = self._merge_infos(before, res["info"], int(before["unfinished"]) * level_cap)
             t = lap("solve", t)
             first = False
-            left = torch.tensor([int(res["info"]["unfinished"])], dtype=torch.int64, device=dev)
-            comm.all_reduce(left, dist.ReduceOp.SUM)
-            done = int(left.item()) == 0
+            # ONE all-reduce per solve step: is anybody left (a maximum says so as well as a sum), and the rounds the ranks took
+            left = torch.tensor([int(res["info"]["unfinished"]), int(res["info"]["rounds"])], dtype=torch.int64, device=dev)
+            comm.all_reduce(left, dist.ReduceOp.MAX)
+            left_host = left.tolist()
+            done = int(left_host[0]) == 0
+            rounds_all = int(left_host[1])
             t = lap("reduce", t)
             if done:
                 break
             if level_cap + 1 >= max_rounds:
                 raise _lib.TknnError(-4, "max_rounds reached with unfinished queries")
             level_cap += 1  # stragglers need the next radius level: widen the halo by its shell and solve them again
-        rounds = torch.tensor([int(res["info"]["rounds"])], dtype=torch.int64, device=dev)
-        comm.all_reduce(rounds, dist.ReduceOp.MAX)
         info = dict(res["info"])
-        info["rounds"] = int(rounds.item())
+        info["rounds"] = rounds_all
         info["halo_exchanges"] = exchanges
         info["halo_points"] = halo_points
         info["halo_points_by_exchange"] = round_halo  # the first exchange's halo, then the shells of the straggler rounds
@@ -531,57 +532,101 @@ class ShardedTrueKNN:
         comm, dev = self.comm, self.device
         eps32 = float(np.float32(eps))
         m = len(self.points)
+        phase = {"setup": 0.0, "cluster": 0.0, "propagate": 0.0, "number": 0.0, "assign": 0.0}
+        profile = self.profile
+
+        def lap(name, t0):  # (TKNN_SHARD_PROFILE / bench.py's instrumented steps: a device synchronisation per phase)
+            if profile:
+                if dev.type == "cuda":
+                    torch.cuda.synchronize(dev)
+                phase[name] += (time.perf_counter() - t0) * 1e3
+            return time.perf_counter()
+
+        t = time.perf_counter()
         halo, counts_in, sent_local, ids = self._db_setup(eps32, reuse=_reuse_setup)
+        t = lap("setup", t)
         local = self.db_engine.dbscan(eps32, min_pts)
+        t = lap("cluster", t)
         core = local["core"].to(dev).bool()
-        comp = local["labels"].to(dev).long()
         big = torch.iinfo(torch.int64).max
-        lab = torch.where(core, ids.long(), torch.full_like(ids, big, dtype=torch.int64))
-        ncomp = int(comp[core].max().item()) + 1 if bool(core.any()) else 0
-        core_idx = torch.nonzero(core).flatten()
+        # Label propagation works on CLUSTERS, not points (round 4; the per-point form spent 160 ms of a 174 ms step in
+        # scatter-reduces of ten million values onto 83 addresses): lab_comp[c] = the smallest global core id known for local
+        # cluster c.  Per point there is one step before the rounds (the clusters' own minima: tknnSegmentMin) and one gather
+        # after them; a round moves the values of the halo rows and touches the clusters they belong to.
+        seg = torch.where(core, local["labels"].to(dev).int(), torch.full((len(ids),), -1, dtype=torch.int32, device=dev))  # cluster of a core point, else -1
+        ncomp = int((local.get("info") or {}).get("clusters", -1))
+        if ncomp < 0:  # (an engine that does not say)
+            ncomp = int(seg.max().item()) + 1 if len(seg) else 0
+        ncomp = max(ncomp, 0)
+        lab_comp = torch.full((max(ncomp, 1),), big, dtype=torch.int64, device=dev)
+        self._seg_min(seg, ids.long(), lab_comp)
+        seg_halo = seg[m:]
+        seg_sent = [seg[:m][sent_local[p]] if len(sent_local[p]) else seg[:0] for p in range(comm.world)]
+        offs = np.concatenate([[0], np.cumsum(counts_in)])
+        big_row = torch.full((1,), big, dtype=torch.int64, device=dev)
+
+        def of_clusters(which):  # the clusters' labels for a list of rows (a row that is not core: nothing to say)
+            return torch.where(which >= 0, lab_comp[which.clamp(min=0).long()], big_row).reshape(-1, 1).contiguous()
+
         rounds = 0
         while True:
             rounds += 1
-            before = lab[:m].clone()
-            if ncomp:
-                cmin = torch.full((ncomp,), big, dtype=torch.int64, device=dev)
-                cmin.scatter_reduce_(0, comp[core_idx], lab[core_idx], "amin")
-                lab[core_idx] = cmin[comp[core_idx]]
+            before = lab_comp.clone()
             # copies -> owners (minimum)
-            offs = np.concatenate([[0], np.cumsum(counts_in)])
-            back = [lab[m + int(offs[s]): m + int(offs[s + 1])].reshape(-1, 1).contiguous() for s in range(comm.world)]
+            back = [of_clusters(seg_halo[int(offs[s_]): int(offs[s_ + 1])]) for s_ in range(comm.world)]
             # (both directions answer rows that travelled before: every count is known at both ends, none is exchanged)
             expect_back = [int(len(sent_local[p])) for p in range(comm.world)]
             expect_back[comm.rank] = int(len(back[comm.rank]))
             for p, vals in enumerate(comm.exchange_rows(back, 1, torch.int64, dev, counts_in=expect_back)):
                 if p != comm.rank and len(vals):
-                    lab[:m].scatter_reduce_(0, sent_local[p], vals.flatten(), "amin")
+                    self._seg_min(seg_sent[p], vals.flatten(), lab_comp)
             # owners -> copies
-            fwd = [lab[:m][sent_local[p]].reshape(-1, 1).contiguous() for p in range(comm.world)]
+            fwd = [of_clusters(seg_sent[p]) for p in range(comm.world)]
             expect_fwd = [int(c) for c in counts_in]
             expect_fwd[comm.rank] = int(len(fwd[comm.rank]))
             new = comm.exchange_rows(fwd, 1, torch.int64, dev, counts_in=expect_fwd)
             new[comm.rank] = new[comm.rank][:0]
             if len(halo):
-                lab[m:] = torch.cat(new, dim=0).flatten()
-            changed = torch.tensor([int(bool((lab[:m] != before).any()))], dtype=torch.int64, device=dev)
+                self._seg_min(seg_halo, torch.cat(new, dim=0).flatten(), lab_comp)
+            changed = torch.tensor([int(bool((lab_comp != before).any()))], dtype=torch.int64, device=dev)
             comm.all_reduce(changed, dist.ReduceOp.MAX)
             if int(changed.item()) == 0:
                 break
-        # cluster numbers: ascending smallest core id over ALL ranks
-        mine = torch.unique(lab[:m][core[:m]])
+        t = lap("propagate", t)
+        # cluster numbers: ascending smallest core id over ALL ranks (of the clusters that have a core point of MINE)
+        own_min = torch.full_like(lab_comp, big)
+        self._seg_min(seg[:m], ids[:m].long(), own_min)
+        mine = torch.unique(lab_comp[own_min != big])
         width = torch.tensor([len(mine)], dtype=torch.int64, device=dev)
         comm.all_reduce(width, dist.ReduceOp.MAX)
         padded = torch.full((max(int(width.item()), 1),), big, dtype=torch.int64, device=dev)
         padded[: len(mine)] = mine
         everyone = torch.unique(comm.all_gather(padded).flatten())
         everyone = everyone[everyone != big]
-        number = torch.searchsorted(everyone, lab.clamp(max=int(everyone[-1].item()) if len(everyone) else 0))
-        known = core & (lab != big)
-        core_label = torch.where(known, number, torch.full_like(number, -1)).int()
+        number_comp = torch.searchsorted(everyone, lab_comp.clamp(max=int(everyone[-1].item()) if len(everyone) else 0)).int()
+        core_label = torch.where(seg >= 0, number_comp[seg.clamp(min=0).long()], torch.full_like(seg, -1))
+        t = lap("number", t)
         labels = self.db_engine.dbscan_assign(eps32, core_label)
-        info = {"clusters": int(len(everyone)), "rounds": rounds, "label_rounds": rounds, "halo_points": int(len(halo))}
+        t = lap("assign", t)
+        info = {"clusters": int(len(everyone)), "rounds": rounds, "label_rounds": rounds, "halo_points": int(len(halo)), "halo_exchanges": 1}
+        # the tile's own clustering as its engine reports it (device times of the three traversal kernels, work counters)
+        eng_info = dict(local.get("info") or {})
+        eng_info["n_clustered"] = int(len(ids))
+        info["engine"] = eng_info
+        if profile:
+            info["phase_ms"] = phase
         return {"labels": labels[:m].to(dev), "core": core[:m], "info": info}
+
+    def _seg_min(self, seg, val, out):
+        """out[seg[i]] = min(out[seg[i]], val[i]) for seg[i] >= 0: the engine's kernel (tknnSegmentMin) if it has one, else torch"""
+        if len(seg) == 0:
+            return out
+        if hasattr(self.db_engine, "segment_min"):
+            return self.db_engine.segment_min(seg.int(), val, out)
+        keep = seg >= 0
+        if bool(keep.any()):
+            out.scatter_reduce_(0, seg[keep].long(), val[keep], "amin")
+        return out
 
     def _db_setup(self, eps32, reuse=False):
         """The engine over my tile plus a halo of radius 2 eps (see dbscan).  ``reuse``: the auto-eps loop's last growth

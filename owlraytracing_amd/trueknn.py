@@ -240,6 +240,18 @@ class TrueKNN:
                                                   ctypes.c_void_p(labels.data_ptr()), ctypes.byref(info), self._stream()))
         return labels
 
+    def segment_min(self, segment, value, out):
+        """out[segment[i]] = min(out[segment[i]], value[i]) for segment[i] >= 0, in place (tknnSegmentMin): ``segment`` (n,)
+        int32, ``value`` (n,) int64, ``out`` (m,) int64 preset by the caller, all on the engine's device."""
+        torch = self._torch
+        if segment.dtype != torch.int32 or value.dtype != torch.int64 or out.dtype != torch.int64 or segment.shape != value.shape:
+            raise ValueError("segment_min: int32 segments, int64 values of the same shape, int64 out")
+        with torch.cuda.device(self.device):
+            segment, value = segment.contiguous(), value.contiguous()
+            _lib.check(self._lib.tknnSegmentMin(self._h, ctypes.c_void_p(segment.data_ptr()), ctypes.c_void_p(value.data_ptr()), int(segment.numel()),
+                                                ctypes.c_void_p(out.data_ptr()), self._stream()))
+        return out
+
     def export_tree(self):
         """Host copies of the LBVH for tests: nodes (n-1,8) uint32 view, ropes, prim ids."""
         torch = self._torch

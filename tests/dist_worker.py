@@ -111,11 +111,20 @@ def make_points(name, n):
 def main():
     engine, n, k, name, out = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), sys.argv[4], sys.argv[5]
     use_gpu = engine == "hip"
-    dist.init_process_group("gloo")  # host-staged messages: CPU ranks, or ranks sharing one GPU
+    # DIST_BACKEND=gloo (default): host-staged messages -- CPU ranks, or ranks sharing one GPU.  DIST_BACKEND=nccl: RCCL, device
+    # tensors in every collective and point-to-point message, one rank per GPU (bench.py's way; on a one-GPU box: one rank)
+    backend = os.environ.get("DIST_BACKEND", "gloo")
+    if backend == "nccl":
+        local = int(os.environ.get("LOCAL_RANK", "0"))
+        torch.cuda.set_device(local)
+        dev = torch.device("cuda", local)
+        dist.init_process_group("nccl", device_id=dev)
+    else:
+        dist.init_process_group(backend)
+        dev = torch.device("cuda", 0) if use_gpu else torch.device("cpu")
+        if use_gpu:
+            torch.cuda.set_device(0)
     rank, world = dist.get_rank(), dist.get_world_size()
-    dev = torch.device("cuda", 0) if use_gpu else torch.device("cpu")
-    if use_gpu:
-        torch.cuda.set_device(0)
     pts = make_points(name, n)
     lo, hi = n * rank // world, n * (rank + 1) // world  # arbitrary initial ownership: contiguous slices
     solver = tkd.ShardedTrueKNN(dev, engine_factory=None if use_gpu else CheckerEngine, halo_levels=int(os.environ.get("HALO_LEVELS", "1")))

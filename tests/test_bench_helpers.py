@@ -99,3 +99,35 @@ def test_one_red_check_fails_the_run_whatever_the_others_say():
     # and the main body folds its checks through that function only
     src = open(os.path.join(ROOT, "bench.py")).read()
     assert "failed = not ok" not in src.split("def dbscan_config3_leg")[0]
+
+
+def test_multi_rank_line_names_the_set_it_timed(monkeypatch):
+    """with N > 1 the default run timed N x 10 M points under the metric "10M pts".  Now the headline of a default
+    N-rank run is BASELINE's 10 M set cut into N tiles (strong), N x 10 M and (N = 8) the 100 M set are sub-objects, every
+    metric string names the size that ran, and the exchange is labelled by the backend that carried it."""
+    import argparse
+
+    bench = _bench()
+    monkeypatch.setattr(bench, "committed_profile", lambda kernel, n, k: (None, "no PMC record for this kernel and size"))
+    assert bench.size_label(10_000_000) == "10M" and bench.size_label(80_000_000) == "80M" and bench.size_label(1234) == "1234"
+    assert "RCCL" in bench.exchange_label("nccl") and "RCCL" not in bench.exchange_label("gloo") and "gloo" in bench.exchange_label("gloo")
+    info = {"dominant_kernel_ms": 1.0, "total_intersections": 4_900_000, "total_active_rounds": 250_000, "dominant_kernel_launches": 1, "kernel_used": 3,
+            "rounds": 4, "point_tests": 50_000_000, "node_tests": 2_000_000}
+    args = argparse.Namespace(k=10, steps=10, warmup=2)
+    for world, n_total, scaling in ((8, 10_000_000, "strong"), (8, 80_000_000, "weak"), (8, 100_000_000, "strong"), (1, 10_000_000, "weak")):
+        sharded = world > 1
+        line = bench.trueknn_line(args, info, [info], 1e9, 1.0, n_total, n_total // world, world, sharded, 0.0025,
+                                  "; %d Morton tiles, %s" % (world, bench.exchange_label("nccl")) if sharded else "", scaling)
+        assert line["metric"] == "kNN queries/sec (%s pts, k=10)" % bench.size_label(n_total)
+        assert line["config"]["n_points_total"] == n_total and str(n_total) in line["config"]["workload"]
+        if sharded:
+            assert "RCCL" in line["config"]["workload"] and ("cut into 8 tiles" in line["config"]["workload"]) == (scaling == "strong")
+        assert set(line["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"}
+    run = {"value": 2e9, "ms_per_step": 40.0, "steps": 5, "warmup": 1, "n_points_total": 80_000_000, "start_radius": 0.00125,
+           "ranks": [{"rank": j, "points": 10_000_000, "halo_points": 300_000, "halo_exchanges": 1, "ms_per_step_own_clock": 39.0,
+                      "phase_ms": {"select": 0.4, "exchange": 0.3, "halo_build": 0.3, "solve": 7.0, "reduce": 0.1}, "kernel_ms": 6.8} for j in range(8)],
+           "phase_ms": {"select": 0.4, "exchange": 0.3, "halo_build": 0.3, "solve": 7.0, "reduce": 0.1}, "halo_points": 2_400_000, "halo_exchanges": 1}
+    sub = bench.sub_object(run, 8, 10, "weak")
+    assert sub["metric"] == "kNN queries/sec (80M pts, k=10)" and sub["scaling"] == "weak" and sub["n_gpus"] == 8
+    assert len(sub["ranks"]) == 8 and set(sub["phase_ms"]) == {"select", "exchange", "halo_build", "solve", "reduce"}
+    json.dumps(sub)  # the sub-object goes into the JSON line as it is

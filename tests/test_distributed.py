@@ -264,3 +264,27 @@ def test_halo_select_matches_a_plain_selection():
             assert back[i] == tuple(pts[(i - 11) // 3])
     assert ids[100] in rows[:, 3].contiguous().view(torch.int32).numpy()
     eng.close()
+
+
+@pytest.mark.gpu
+def test_rccl_branch_with_one_rank(tmp_path):
+    """every multi-rank test initialised gloo, so the branch a real multi-GPU run takes -- backend nccl (= RCCL):
+    `init_process_group("nccl", device_id=...)`, DEVICE tensors through all_reduce / all_gather / batch_isend_irecv, the
+    fixed-capacity exchange's no-peer path -- had never run inside the suite.  One rank is what a one-GPU box allows (RCCL
+    refuses two ranks on one device); TrueKNN with a straggler round, RT-DBSCAN and the auto-eps loop go through it."""
+    from dist_worker import make_points
+    nccl = {"DIST_BACKEND": "nccl"}
+    n, k = 150_000, 10
+    got = _run("hip", 1, n, k, "uniform", tmp_path, 29681, dict(nccl, HALO_LEVELS="1"))
+    _check(got, "uniform", n, k)
+    got = _run("hip", 1, 80_000, 6, "clustered", tmp_path, 29682, dict(nccl, HALO_LEVELS="0", START_RADIUS="0.001"))
+    _check(got, "clustered", 80_000, 6, r0=0.001)
+    assert len(got["halo_by_exchange"]) >= 2  # (stragglers: more than one round of the all-reduce)
+    n, eps, min_pts = 120_000, float(np.float32(0.012)), 5
+    got = _run("hip", 1, n, 4, "clustered", tmp_path, 29683, dict(nccl, DBSCAN_EPS=repr(eps), DBSCAN_MINPTS=str(min_pts)))
+    _check_dbscan(got, "clustered", n, eps, min_pts)
+    eps0, max_noise = float(np.float32(0.0015)), 0.03
+    got = _run("hip", 1, n, 4, "clustered", tmp_path, 29684, dict(nccl, DBSCAN_EPS=repr(eps0), DBSCAN_MINPTS=str(min_pts), DBSCAN_MAX_NOISE=repr(max_noise)))
+    ref = oracle.dbscan_auto(make_points("clustered", n), eps0, min_pts, max_noise)
+    assert int(got["eps_rounds"]) == ref["rounds"] and float(got["eps"]) == ref["eps"] and int(got["noise"]) == ref["noise"]
+    assert np.array_equal(got["labels"], ref["labels"]) and np.array_equal(got["core"], ref["core"])
