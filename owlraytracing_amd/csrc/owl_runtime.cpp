@@ -24,6 +24,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <map>
@@ -268,7 +269,11 @@ struct Geom : SBTObject {
 
 enum class BufferKind { Device, Managed, HostPinned };
 struct Buffer : Object {
-  Buffer(Context *c, BufferKind bk, OWLDataType t, size_t n) : Object(c, Kind::Buffer), bkind(bk), type(t), count(n) {}
+  Buffer(Context *c, BufferKind bk, OWLDataType t, size_t n) : Object(c, Kind::Buffer), bkind(bk), type(t), count(n) {
+    static int created = 0;
+    serial = created++;
+  }
+  int serial;  // in the order of creation (the dump hook of owlContextDestroy names its files by it)
   ~Buffer() override { release(); }
   BufferKind bkind;
   OWLDataType type;
@@ -947,6 +952,29 @@ OWL_API OWLContext owlContextCreate(int32_t *requestedDeviceIDs, int numDevices)
   return (OWLContext)h;
 }
 
+// OWL_MI355X_DUMP_BUFFERS=<directory> (tests, and a maintainer comparing runs: INTEGRATION.md): when a context is destroyed,
+// the final contents of its MANAGED buffers -- in the unchanged samples: the frameBuffer of Neigh records, which no API call
+// exports and whose dump loop the reference has commented out (hostCode.cpp:312-321) -- go to
+// <directory>/managed_<creation index>_<bytes>.bin.
+static void dump_managed_buffers(const std::set<Handle *> &all) {
+  const char *dir = getenv("OWL_MI355X_DUMP_BUFFERS");
+  if (!dir || !*dir) return;
+  for (Handle *h : all) {
+    if (!h || !h->obj || h->obj->kind != Kind::Buffer) continue;
+    auto b = std::static_pointer_cast<Buffer>(h->obj);
+    if (b->bkind != BufferKind::Managed || !b->ptr || !b->bytes()) continue;
+    std::vector<uint8_t> host(b->bytes());
+    // (mirror form: the host's copy is the newer one if it holds the pointer and no launch has run since its last refresh)
+    const void *src = (b->mirror && b->handed_out && !b->device_newer) ? b->mirror : b->ptr;
+    if (hipMemcpy(host.data(), src, b->bytes(), hipMemcpyDefault) != hipSuccess) continue;
+    const std::string path = std::string(dir) + "/managed_" + std::to_string(b->serial) + "_" + std::to_string(b->bytes()) + ".bin";
+    if (FILE *f = std::fopen(path.c_str(), "wb")) {
+      std::fwrite(host.data(), 1, host.size(), f);
+      std::fclose(f);
+    }
+  }
+}
+
 OWL_API void owlContextDestroy(OWLContext context) {
   auto c = CTX(context);
   (void)hipDeviceSynchronize();
@@ -955,6 +983,7 @@ OWL_API void owlContextDestroy(OWLContext context) {
     std::lock_guard<std::mutex> g(c->mtx);
     all.swap(c->handles);
   }
+  dump_managed_buffers(all);
   for (Handle *h : all) delete h;
   c->miss_by_ray_type.clear();
   if (c->stream) (void)hipStreamDestroy(c->stream);
