@@ -1071,10 +1071,16 @@ __global__ void __launch_bounds__(kDbUnionBlock) __attribute__((amdgpu_waves_per
         const int j = __ffsll((long long)todo) - 1;
         todo &= todo - 1ull;
         const DbCand e = cand[j];
-        const int32_t e_end = e.ref >= 0 ? e.ref : ~e.ref;
-        const int32_t e_first = min(e_end, e.other), e_last = max(e_end, e.other);
-        const bool hit = (e.lo[0] - r <= ahi[0]) & (alo[0] <= e.hi[0] + r) & (e.lo[1] - r <= ahi[1]) & (alo[1] <= e.hi[1] + r) &
-                         (e.lo[2] - r <= ahi[2]) & (alo[2] <= e.hi[2] + r) & (e_last > a_last);
+        // (the staged node is the same in every lane: its slot range as scalars)
+        const int32_t e_ref = __builtin_amdgcn_readfirstlane(e.ref), e_other = __builtin_amdgcn_readfirstlane(e.other);
+        const int32_t e_end = e_ref >= 0 ? e_ref : ~e_ref;
+        const int32_t e_first = min(e_end, e_other), e_last = max(e_end, e_other);
+        // within reach along every axis: the largest separation of the two boxes against r -- subtractions and maxima instead
+        // of six compares and their mask operations (a third of this loop's slow instructions; as conservative as
+        // fl(e.lo - r) <= a.hi: a difference that is <= r before rounding is <= r after it)
+        const float sx = fmaxf(e.lo[0] - ahi[0], alo[0] - e.hi[0]), sy = fmaxf(e.lo[1] - ahi[1], alo[1] - e.hi[1]),
+                    sz = fmaxf(e.lo[2] - ahi[2], alo[2] - e.hi[2]);
+        const bool hit = (fmaxf(fmaxf(sx, sy), sz) <= r) & (e_last > a_last);
         if (__ballot(hit) == 0ull) continue;
         if (!((m_tight >> j) & 1ull)) {
           m_open |= 1ull << j;
