@@ -94,6 +94,19 @@ struct BlockState {
 };
 static __shared__ BlockState owl_block_state;
 
+}  // namespace device
+}  // namespace owl
+// The layout of what the host hands to device code (LaunchDesc, the records) is part of this header AND of libowl_mi355x.so:
+// a code object built with one and launched by the other would read its arguments at the wrong offsets.  The code
+// object carries the header's layout word, the host compares it with its own when it loads the module (owlBuildPrograms) and
+// refuses a mismatch.  High 16 bits: revision of this header's host-visible structs; low 16: sizeof(LaunchDesc).
+#ifndef OWL_MI355X_DEVICE_ABI /* (tests build a module with another word to see it refused) */
+#define OWL_MI355X_DEVICE_ABI ((2u << 16) | (unsigned)sizeof(owl::device::LaunchDesc))
+#endif
+extern "C" __attribute__((weak, used, visibility("default"))) __device__ const unsigned owl_mi355x_device_abi = OWL_MI355X_DEVICE_ABI;
+namespace owl {
+namespace device {
+
 __device__ __forceinline__ BlockState &state() { return owl_block_state; }
 __device__ __forceinline__ uint32_t tid() {
   return threadIdx.x + blockDim.x * (threadIdx.y + blockDim.y * threadIdx.z);

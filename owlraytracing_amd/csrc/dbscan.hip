@@ -1667,6 +1667,12 @@ void Engine::dbscan(float eps, int min_pts, int32_t *d_labels, uint8_t *d_core, 
   const unsigned blocks = (unsigned)((n + kDbBlock - 1) / kDbBlock);
   a.diag_out = counters_ + 20;
   a.stats = counters_ + kCounters;  // striped (db_add_stats); [0..5]: node / point tests of the three traversal kernels
+  if (db_side_pending_) {
+    // a call that threw between its side launch and its rejoin has left db_border_walk_kernel running on the workspace
+    // and the counters this call is about to reset: nothing of this call before that kernel has ended
+    OWLMI_HIP(hipStreamWaitEvent(s, ev_side_b_, 0));
+    db_side_pending_ = false;
+  }
   OWLMI_HIP(hipMemsetAsync(counters_, 0, (kCounters + kDbStripes * 8) * sizeof(unsigned long long), s));  // ... [19]: length of the label pass's list
   const unsigned walk_grid = blocks < 2048u ? blocks : 2048u;  // grid-stride over lists whose lengths only the device knows
   hipEvent_t e0 = ev_a_, e1 = ev_b_;
@@ -1695,6 +1701,7 @@ void Engine::dbscan(float eps, int min_pts, int32_t *d_labels, uint8_t *d_core, 
     OWLMI_HIP(hipStreamWaitEvent(db_side_, ev_side_a_, 0));
     hipLaunchKernelGGL(db_border_walk_kernel, dim3(walk_grid), dim3(kDbBlock), 0, db_side_, a, not_core, counters_ + 19, border_lists, border_per, (long long)n);
     OWLMI_HIP(hipEventRecord(ev_side_b_, db_side_));
+    db_side_pending_ = true;  // (until some stream waits for it: below, or at the top of the next call if this one throws in between)
   }
   if (core_label) {
     hipLaunchKernelGGL(db_assign_kernel, dim3(blocks), dim3(kDbBlock), 0, s, a, core_label);
@@ -1799,7 +1806,10 @@ void Engine::dbscan(float eps, int min_pts, int32_t *d_labels, uint8_t *d_core, 
   OWLMI_HIP(hipMemcpyAsync(&last[0], a.rank + (n - 1), 4, hipMemcpyDeviceToHost, s));
   OWLMI_HIP(hipMemcpyAsync(&last[1], is_root + (n - 1), 4, hipMemcpyDeviceToHost, s));
   OWLMI_HIP(hipEventRecord(ev_f_, s));
-  if (side) OWLMI_HIP(hipStreamWaitEvent(s, ev_side_b_, 0));
+  if (side) {
+    OWLMI_HIP(hipStreamWaitEvent(s, ev_side_b_, 0));
+    db_side_pending_ = false;
+  }
   // labels by slot first and a gather to the rows (default), or scattered straight to the rows (TKNN_DB_LABEL=scatter: A/B).
   // The caller's arrays must allow 16-byte stores for the gather (hipMalloc'd ones do).
   const char *label_env = getenv("TKNN_DB_LABEL");

@@ -193,6 +193,21 @@ struct Module : Object {
     if (mod) return;
     if (!code) fail("owlModuleCreate was given a NULL code pointer");
     OWL_HIP(hipModuleLoadData(&mod, code));
+    {
+      // the device header's layout word against this library's (include/owl/device_runtime.h, OWL_MI355X_DEVICE_ABI)
+      hipDeviceptr_t word = nullptr;
+      size_t bytes = 0;
+      unsigned theirs = 0;
+      const unsigned mine = (2u << 16) | (unsigned)sizeof(rec::LaunchDesc);
+      if (hipModuleGetGlobal(&word, &bytes, mod, "owl_mi355x_device_abi") != hipSuccess || bytes != sizeof(unsigned)) {
+        (void)hipGetLastError();
+        fail("the module carries no owl_mi355x_device_abi word: it was built with another (older) owl/device_runtime.h than this library's");
+      }
+      OWL_HIP(hipMemcpy(&theirs, word, sizeof theirs, hipMemcpyDeviceToHost));
+      if (theirs != mine)
+        fail("device code was built with another revision of owl/device_runtime.h (layout word " + std::to_string(theirs) + ", this library's is " +
+             std::to_string(mine) + "): rebuild the device programs against this library's headers");
+    }
     if (hipModuleGetGlobal(&params_ptr, &params_bytes, mod, "optixLaunchParams") != hipSuccess) {
       (void)hipGetLastError();
       params_ptr = nullptr;

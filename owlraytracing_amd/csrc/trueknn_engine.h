@@ -125,6 +125,7 @@ class Engine {
   // dbscan(): the walks of the points that are not core run beside the group unions on a stream of their own
   hipStream_t db_side_ = nullptr;
   hipEvent_t ev_side_a_ = nullptr, ev_side_b_ = nullptr;
+  bool db_side_pending_ = false;  // a side launch was recorded in ev_side_b_ and no stream has been made to wait for it yet
   hipEvent_t ev_g_ = nullptr, ev_h_ = nullptr;  // dbscan(): around what runs between the two union launches
   // the packet kernel's solve launches the tie pass behind itself, before its one host round trip: set if
   // that launch has seen every flagged row (no tail ran, the list held them all)

@@ -417,6 +417,18 @@ static void expect_throw(const char *what, const std::function<void()> &f, const
 static int run_errors(int argc, char **argv) {
   if (argc < 3) return 2;
   std::vector<char> code = read_file(argv[2]);
+  if (argc >= 4) {
+    // a module built against another revision of owl/device_runtime.h (its layout word differs from the library's): refused
+    // when it is loaded, not launched with its arguments at the wrong offsets
+    std::vector<char> stale = read_file(argv[3]);
+    OWLContext c2 = owlContextCreate(nullptr, 1);
+    OWLModule m2 = owlModuleCreate(c2, stale.data());
+    OWLVarDecl gv[] = {{"centers", OWL_BUFPTR, 0}, {"radius", OWL_FLOAT, 8}, {nullptr, OWL_INVALID_TYPE, 0}};
+    OWLGeomType t2 = owlGeomTypeCreate(c2, OWL_GEOMETRY_USER, 16, gv, -1);
+    owlGeomTypeSetBoundsProg(t2, m2, "Balls");
+    expect_throw("device code of another header revision", [&] { owlBuildPrograms(c2); }, "another revision");
+    owlContextDestroy(c2);
+  }
   OWLContext ctx = owlContextCreate(nullptr, 1);
   OWLModule mod = owlModuleCreate(ctx, code.data());
   OWLVarDecl geomVars[] = {{"centers", OWL_BUFPTR, 0}, {"radius", OWL_FLOAT, 8}, {nullptr, OWL_INVALID_TYPE, 0}};

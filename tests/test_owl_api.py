@@ -62,7 +62,7 @@ def _need_driver():
 @pytest.mark.gpu
 def test_error_conventions():
     _need_driver()
-    r = subprocess.run([DRIVER, "errors", RADIUS_HSACO], capture_output=True, text=True, timeout=120)
+    r = subprocess.run([DRIVER, "errors", RADIUS_HSACO, os.path.join(BUILD, "stale_abi_programs.hsaco")], capture_output=True, text=True, timeout=120)
     print(r.stdout, r.stderr)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "failures=0" in r.stdout and "FAIL" not in r.stdout
