@@ -648,6 +648,17 @@ def dbscan_rooflines(info, infos, n_local, min_pts):
                       + (" (the two launches; db_uniform_kernel between them is not in it)" if nm == "union_ms" else ""),
         }
         rec, why_not = committed_profile(kernel_name, n_local, min_pts)
+        if rec and nm == "label_ms":
+            # round 4: the labels stay by slot in db_label_kernel and a second launch, db_rows_from_slots_kernel, carries them to
+            # the rows (label_ms spans both): the pass's traffic is the two kernels' together
+            rec2, why2 = committed_profile("db_rows_from_slots_kernel", n_local, min_pts)
+            if rec2:
+                rec = dict(rec)
+                for kk in ("bytes_per_launch", "FETCH_SIZE_KB_per_launch", "WRITE_SIZE_KB_per_launch"):
+                    rec[kk] = rec[kk] + rec2[kk]
+                r["kernels_of_the_pass"] = ["db_label_kernel", "db_rows_from_slots_kernel"]
+            else:
+                rec, why_not = None, "db_rows_from_slots_kernel: " + str(why2)
         if rec:
             r["traffic"] = rec["bytes_per_launch"]
             r["traffic_over_algorithmic"] = rec["bytes_per_launch"] / max(alg_bytes, 1)

@@ -68,8 +68,12 @@ def main():
     which = sys.argv[1:] or ["gmm", "taxi", "ksweep", "sizes", "dbscan", "dbscan_auto", "sample"]
     if "ksweep" in which:  # BASELINE config 2's set at other k (team kernels: 1, 2 or 4 list registers per lane)
         pts = datasets.uniform3d(10_000_000, seed=0)
-        for k in (5, 16, 32, 50, 64):
+        for k in (5, 16, 32, 33, 50, 64, 65, 100):  # (k > 64: the team walk with the lists in memory)
             timed_solve("trueknn_uniform3d_10M_k%d" % k, pts, k, datasets.start_radius(len(pts), k), kernels=(3,))
+        del pts
+        pts = datasets.uniform3d(1_000_000, seed=0)
+        for k in (256, 1024):
+            timed_solve("trueknn_uniform3d_1M_k%d" % k, pts, k, datasets.start_radius(len(pts), k), kernels=(3,))
         del pts
     if "sizes" in which:  # config 4's whole 100 M-point set on ONE GPU
         for n in (50_000_000, 100_000_000):

@@ -151,6 +151,8 @@ def main():
         if "dbscan_config3" in b:  # the default run's RT-DBSCAN leg: BASELINE config 3 (10 M points, minPts 4)
             for name, rr in b["dbscan_config3"]["roofline"].items():
                 jobs.append((name, int(rr.get("launches_per_step", 1)), "%s:n=%d:k=%d" % (name, 10_000_000, 4)))
+            # (round 4: the label pass's second launch, whose traffic bench.py adds to db_label_kernel's)
+            jobs.append(("db_rows_from_slots_kernel", 1, "db_rows_from_slots_kernel:n=%d:k=%d" % (10_000_000, 4)))
         for name, rr in r.get("kernels", {}).items():  # bench.py --workload dbscan
             if name != r["kernel"]:
                 jobs.append((name, int(rr.get("launches_per_step", 1)), "%s:n=%d:k=%d" % (name, n_local, k_main)))
