@@ -173,6 +173,14 @@ TKNN_API int tknnHaloSelect(tknnEngine e, const float *d_boxes, const int32_t *d
                             int32_t npeers, int64_t *d_counts, const int64_t *d_offsets, float *d_rows,
                             void *stream);
 
+/* The same in ONE pass, for a caller that knows how many rows each peer's segment may hold (both ends of a pair agree on the
+ * size of their message from the pair's last exchange): rows are written at d_offsets[peer] .. + d_caps[peer], rows that do not fit
+ * are dropped, d_counts[peer] receives the exact number of rows selected (> d_caps[peer]: the caller must fall back to
+ * tknnHaloSelect for that peer).  No count pass, no host round trip before the rows exist.  Marks the boundary queries like the
+ * count pass of tknnHaloSelect. */
+TKNN_API int tknnHaloSelectFixed(tknnEngine e, const float *d_boxes, const int32_t *d_box_peer, int32_t nboxes, int32_t npeers,
+                                 const int64_t *d_caps, const int64_t *d_offsets, float *d_rows, int64_t *d_counts, void *stream);
+
 /* ---- exact kNN on request ---------------------------------------------------
  * tknnSolve reproduces the reference, whose rows are box-candidate kNN, not exact kNN: a query
  * that finished with box half-width r_q never saw points outside that box, although its k-th

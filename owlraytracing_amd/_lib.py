@@ -116,6 +116,8 @@ SIGNATURES = {
                                         ctypes.POINTER(DbscanInfo), ctypes.c_void_p]),
     "tknnDbscanAuto": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_float, ctypes.c_int, ctypes.c_double, ctypes.c_int, ctypes.c_void_p,
                                       ctypes.c_void_p, ctypes.POINTER(DbscanAutoInfo), ctypes.c_void_p]),
+    "tknnHaloSelectFixed": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p,
+                                           ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     "tknnSegmentMin": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p]),
     "tknnDbscanNoise": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_float, ctypes.c_int, ctypes.c_void_p, ctypes.POINTER(ctypes.c_int64),
                                        ctypes.c_void_p]),

@@ -39,6 +39,7 @@ struct SelectArgs {
   const int64_t *offsets;          // npeers: first row of each peer's segment (write pass)
   float4 *rows;                    // write pass
   uint8_t *boundary;               // count pass: per sorted slot, 1 if the point lies inside some peer's box
+  const int64_t *caps;             // one-pass form (tknnHaloSelectFixed): rows a peer's segment holds; what does not fit is counted, not written
 };
 
 __global__ void __launch_bounds__(kSelBlock) block_mask_kernel(SelectArgs a) {
@@ -55,7 +56,10 @@ __global__ void __launch_bounds__(kSelBlock) block_mask_kernel(SelectArgs a) {
   a.block_mask[b] = m;
 }
 
-template <bool WRITE>
+// FIXED: the one-pass form -- segments of a capacity both ends of a pair have agreed on (the message sizes of the pair's last
+// exchange), so no count pass and no host round trip come before the rows are written; the cursors end as the exact counts
+// (a peer whose rows did not fit is found out by them), and the boundary marks of the count pass are set here.
+template <bool WRITE, bool FIXED = false>
 __global__ void __launch_bounds__(kSelBlock) point_select_kernel(SelectArgs a) {
   __shared__ unsigned int cnt[kMaxPeers];
   __shared__ unsigned long long base[kMaxPeers];
@@ -78,7 +82,7 @@ __global__ void __launch_bounds__(kSelBlock) point_select_kernel(SelectArgs a) {
       }
     }
   }
-  if (!WRITE && a.boundary && t < a.n) a.boundary[t] = mine != 0ull;
+  if ((!WRITE || FIXED) && a.boundary && t < a.n) a.boundary[t] = mine != 0ull;
   for (unsigned long long m = mine; m; m &= m - 1) atomicAdd(&cnt[__builtin_ctzll(m)], 1u);
   __syncthreads();
   if (threadIdx.x < a.npeers && cnt[threadIdx.x]) {
@@ -95,14 +99,15 @@ __global__ void __launch_bounds__(kSelBlock) point_select_kernel(SelectArgs a) {
   for (unsigned long long m = mine; m; m &= m - 1) {
     const int peer = __builtin_ctzll(m);
     const unsigned int r = atomicAdd(&cnt[peer], 1u);
-    a.rows[a.offsets[peer] + (int64_t)base[peer] + r] = make_float4(p.x, p.y, p.z, __int_as_float(p.id));
+    const int64_t at = (int64_t)base[peer] + r;
+    if (!FIXED || at < a.caps[peer]) a.rows[a.offsets[peer] + at] = make_float4(p.x, p.y, p.z, __int_as_float(p.id));
   }
 }
 
 }  // namespace
 
 void Engine::halo_select(const float *d_boxes, const int32_t *d_box_peer, int32_t nboxes, int32_t npeers,
-                         int64_t *d_counts, const int64_t *d_offsets, float *d_rows, hipStream_t s) {
+                         int64_t *d_counts, const int64_t *d_offsets, float *d_rows, hipStream_t s, const int64_t *d_caps) {
   if (npeers < 1 || npeers > kMaxPeers) throw ArgError{TKNN_E_ARG, "tknnHaloSelect: 1 <= npeers <= 64"};
   const int64_t n = bvh_.size();
   const LbvhWideView wv = bvh_.wide_view();
@@ -130,7 +135,15 @@ void Engine::halo_select(const float *d_boxes, const int32_t *d_box_peer, int32_
   a.rows = reinterpret_cast<float4 *>(d_rows);
   const unsigned point_blocks = (unsigned)((n + kSelBlock - 1) / kSelBlock);
   a.boundary = boundary_;
-  if (!d_rows) {
+  a.caps = d_caps;
+  if (d_caps) {
+    // one pass: rows into segments of the given capacities, exact counts out (tknnHaloSelectFixed)
+    boundary_valid_ = true;
+    OWLMI_HIP(hipMemsetAsync(a.cursor, 0, kMaxPeers * sizeof(unsigned long long), s));
+    hipLaunchKernelGGL(block_mask_kernel, dim3((a.nblocks + kSelBlock - 1) / kSelBlock), dim3(kSelBlock), 0, s, a);
+    hipLaunchKernelGGL((point_select_kernel<true, true>), dim3(point_blocks), dim3(kSelBlock), 0, s, a);
+    OWLMI_HIP(hipMemcpyAsync(d_counts, a.cursor, (size_t)npeers * sizeof(int64_t), hipMemcpyDeviceToDevice, s));
+  } else if (!d_rows) {
     boundary_valid_ = true;  // (the marks are those of THESE boxes: a point inside a peer's widened cell box is a query
                              // that peer's points can reach, and only such a query -- the halo relation is symmetric)
     OWLMI_HIP(hipMemsetAsync(d_counts, 0, (size_t)npeers * sizeof(int64_t), s));

@@ -734,6 +734,18 @@ int tknnHaloSelect(tknnEngine e, const float *d_boxes, const int32_t *d_box_peer
   });
 }
 
+int tknnHaloSelectFixed(tknnEngine e, const float *d_boxes, const int32_t *d_box_peer, int32_t nboxes, int32_t npeers,
+                        const int64_t *d_caps, const int64_t *d_offsets, float *d_rows, int64_t *d_counts, void *stream) {
+  if (!e || nboxes < 0 || (nboxes > 0 && (!d_boxes || !d_box_peer)) || !d_caps || !d_offsets || !d_rows || !d_counts) {
+    g_last_error = "tknnHaloSelectFixed: need boxes with their peers, capacities, offsets, the row buffer and a place for the counts";
+    return TKNN_E_ARG;
+  }
+  return guarded_on(e, [&] {
+    if (!e->impl.built()) throw owlmi::ArgError{TKNN_E_STATE, "tknnHaloSelectFixed: call tknnBuild first"};
+    e->impl.halo_select(d_boxes, d_box_peer, nboxes, npeers, d_counts, d_offsets, d_rows, (hipStream_t)stream, d_caps);
+  });
+}
+
 int tknnSolve(tknnEngine e, int k, float start_radius, int kernel, int max_rounds, int32_t *d_idx,
               float *d_dist, int64_t *d_intersections, tknnNeigh *d_fb, tknnSolveInfo *info, void *stream) {
   tknnSolveOptions o;

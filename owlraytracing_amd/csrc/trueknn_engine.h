@@ -51,8 +51,9 @@ class Engine {
   void set_halo(const float *d_xyz, const int32_t *d_ids, int64_t m, hipStream_t s);
   LbvhView halo_view() const;
   // halo_select.hip: my points inside any box of each peer, as 16-byte wire rows (count pass: d_rows == nullptr)
+  // (d_caps: the one-pass form -- rows into segments of those capacities, exact counts out, what does not fit dropped)
   void halo_select(const float *d_boxes, const int32_t *d_box_peer, int32_t nboxes, int32_t npeers, int64_t *d_counts,
-                   const int64_t *d_offsets, float *d_rows, hipStream_t s);
+                   const int64_t *d_offsets, float *d_rows, hipStream_t s, const int64_t *d_caps = nullptr);
   double expected_box_population(float radius) const;
   void solve(const SolveArgs &sa, int kernel, tknnSolveInfo *info, hipStream_t s);
   // rewrites the rows whose k-th distance exceeds their final box half-width with exact kNN; returns how many

@@ -169,6 +169,64 @@ class _Comm:
             self._remember(tag, [int(c) for c in counts_in], [len(r) for r in rows_per_peer])
         return [r.to(device) for r in recv]
 
+    def has_caps(self, tag):
+        return (tag, "in") in self._caps
+
+    def caps_out(self, tag):
+        return list(self._caps[(tag, "out")])
+
+    def exchange_fixed(self, messages, starts, counts_dev, tag, device, exact_blocks):
+        """The tagged exchange for rows that were SELECTED straight into fixed-capacity messages (TrueKNN.halo_select_fixed): the
+        messages leave as they are, the headers of what arrives and my own counts come to the host in ONE read -- the step's only
+        round trip before the solve (the two-pass selection had one of its own).  A pair whose rows outgrew its capacity goes
+        through exact-size messages once more; ``exact_blocks()`` then returns the per-peer rows the two-pass selection gives.
+        Returns (rows received per source, rows sent per destination)."""
+        world, me = self.world, self.rank
+        cap_in, cap_out = self._caps[(tag, "in")], self._caps[(tag, "out")]
+        recv, ops = [None] * world, []
+        for p in range(world):
+            if p == me:
+                continue
+            m = messages[starts[p]: starts[p] + cap_out[p] + 1]
+            ops.append(dist.P2POp(dist.isend, self._wire(m), p, group=self.group))
+            recv[p] = torch.empty((cap_in[p] + 1, 4), dtype=torch.float32, device="cpu" if self.staged else device)
+            ops.append(dist.P2POp(dist.irecv, recv[p], p, group=self.group))
+        if ops:
+            for req in dist.batch_isend_irecv(ops):
+                req.wait()
+        peers = [p for p in range(world) if p != me]
+        mine = counts_dev.to(recv[peers[0]].device if peers else counts_dev.device).double()
+        heads = [recv[p][0, :2].double() for p in peers]
+        flat = torch.cat([mine] + heads).tolist()  # the one host round trip: my counts, then (low, high) per source
+        counts_out = [int(c) for c in flat[:world]]
+        counts_in = [0] * world
+        for j, p in enumerate(peers):
+            counts_in[p] = int(flat[world + 2 * j]) + (int(flat[world + 2 * j + 1]) << 24)
+        sent = [messages[starts[p] + 1: starts[p] + 1 + min(counts_out[p], cap_out[p])] for p in range(world)]
+        out = [None] * world
+        again_in = [p for p in peers if counts_in[p] > cap_in[p]]
+        again_out = [p for p in peers if counts_out[p] > cap_out[p]]
+        for p in range(world):
+            if p == me:
+                out[p] = messages[:0]
+            elif p not in again_in:
+                out[p] = recv[p][1:1 + counts_in[p]].to(device)
+        if again_in or again_out:
+            exact = exact_blocks() if again_out else None
+            ops, late = [], {}
+            for p in again_out:
+                sent[p] = exact[p]
+                ops.append(dist.P2POp(dist.isend, self._wire(exact[p].contiguous()), p, group=self.group))
+            for p in again_in:
+                late[p] = torch.empty((counts_in[p], 4), dtype=torch.float32, device="cpu" if self.staged else device)
+                ops.append(dist.P2POp(dist.irecv, late[p], p, group=self.group))
+            for req in dist.batch_isend_irecv(ops):
+                req.wait()
+            for p, t in late.items():
+                out[p] = t.to(device)
+        self._remember(tag, counts_in, counts_out)
+        return out, sent
+
     def _remember(self, tag, counts_in, counts_out):
         """capacities of the next exchange under ``tag``: both ends of a pair derive the same number from the same count"""
         grow = lambda c: int(c) + int(c) // 4 + 64  # noqa: E731
@@ -306,20 +364,10 @@ class ShardedTrueKNN:
         if hasattr(self.engine, "halo_select"):
             # the engine's kernels do the selection on its own Morton-sorted points: widened peer boxes
             # in, per-peer contiguous wire rows out (tknnHaloSelect)
-            boxes, owner = [], []
-            for peer in range(comm.world):
-                if peer == comm.rank:
-                    continue
-                pb = self.tile_boxes[peer]
-                pb = pb[pb[:, 0] <= pb[:, 3]]  # drop empty slots
-                if len(pb) == 0:
-                    continue
-                lo, hi = self._widen(pb, reach)
-                boxes.append(torch.cat([lo, hi], dim=1))
-                owner.append(torch.full((len(pb),), peer, dtype=torch.int32))
-            if not boxes:
+            boxes, owner = self._peer_boxes(reach)
+            if boxes is None:
                 return [self._rows[:0] for _ in range(comm.world)]
-            rows, counts = self.engine.halo_select(torch.cat(boxes), torch.cat(owner), comm.world)
+            rows, counts = self.engine.halo_select(boxes, owner, comm.world)
             self._boundary_marked = True  # the count pass has marked my points inside a peer's box: my boundary queries
             return list(torch.split(rows, counts))
         rows = self._rows
@@ -348,6 +396,24 @@ class ShardedTrueKNN:
                 picked.append(rows[s0:s1][inside])
             blocks.append(torch.cat(picked, dim=0) if picked else rows[:0])
         return blocks
+
+    def _peer_boxes(self, reach):
+        """(boxes (m,6) float32, owner (m,) int32) of every peer's Morton cells widened by ``reach``, or (None, None)"""
+        comm = self.comm
+        boxes, owner = [], []
+        for peer in range(comm.world):
+            if peer == comm.rank:
+                continue
+            pb = self.tile_boxes[peer]
+            pb = pb[pb[:, 0] <= pb[:, 3]]  # drop empty slots
+            if len(pb) == 0:
+                continue
+            lo, hi = self._widen(pb, reach)
+            boxes.append(torch.cat([lo, hi], dim=1))
+            owner.append(torch.full((len(pb),), peer, dtype=torch.int32))
+        if not boxes:
+            return None, None
+        return torch.cat(boxes), torch.cat(owner)
 
     @staticmethod
     def _widen(pb, reach):
@@ -400,6 +466,7 @@ class ShardedTrueKNN:
             return time.perf_counter()
 
         first = True
+        one_pass = False  # the first exchange of this solve selected its rows straight into fixed-capacity messages
         overlapped = False
         halo = None                         # every foreign row received so far (the halo tree's points)
         sent = [None] * comm.world          # ids of my rows each peer holds already
@@ -411,7 +478,24 @@ class ShardedTrueKNN:
                 halo_radius = np.float32(halo_radius * np.float32(2))
             t = time.perf_counter()
             self._boundary_marked = False
-            blocks = self._halo_blocks(halo_radius)
+            tag = ("halo", level_cap, first)
+            # The step's usual form (round 4): both ends of every pair remember how much travelled under this tag, so the rows are
+            # selected straight into messages of that capacity (one pass, no count pass, no host round trip of its own) and the
+            # exchange's one read of the headers also brings my own counts.  The first exchange under a tag, the straggler rounds
+            # (shells) and engines without the one-pass selection go the two-pass way below.
+            fixed = (first and comm.world > 1 and comm.has_caps(tag) and hasattr(self.engine, "halo_select_fixed")
+                     and not (self.overlap and getattr(self.engine, "supports_phases", False)))
+            fixed_sel = None
+            if fixed:
+                reach = float(halo_radius) * (1.0 + 1e-5) + 1e-30
+                boxes, owner = self._peer_boxes(reach)
+                if boxes is None:
+                    fixed = False
+                else:
+                    fixed_sel = self.engine.halo_select_fixed(boxes, owner, comm.world, [0 if p == comm.rank else c for p, c in enumerate(comm.caps_out(tag))])
+                    self._boundary_marked = True
+                    one_pass = True
+            blocks = self._halo_blocks(halo_radius) if not fixed else None
             if not first:
                 # a straggler round: the peers hold what the smaller radius selected -- only the SHELL between the two
                 # radii travels ("only the incremental shell (r_{t-1}, r_t] need be sent after round 1")
@@ -419,10 +503,11 @@ class ShardedTrueKNN:
                     if p != comm.rank and len(blocks[p]) and sent[p] is not None and len(sent[p]):
                         ids_p = blocks[p][:, 3].contiguous().view(torch.int32)
                         blocks[p] = blocks[p][~torch.isin(ids_p, sent[p])]
-            for p in range(comm.world):
-                if p != comm.rank and len(blocks[p]):
-                    ids_p = blocks[p][:, 3].contiguous().view(torch.int32)
-                    sent[p] = ids_p if sent[p] is None else torch.cat([sent[p], ids_p])
+            if not fixed:
+                for p in range(comm.world):
+                    if p != comm.rank and len(blocks[p]):
+                        ids_p = blocks[p][:, 3].contiguous().view(torch.int32)
+                        sent[p] = ids_p if sent[p] is None else torch.cat([sent[p], ids_p])
             t = lap("select", t)
             two_phases = (first and self.overlap and self._boundary_marked and getattr(self.engine, "supports_phases", False)
                           and dev.type == "cuda" and k <= 64 and self.kernel in (_lib.KERNEL_AUTO, _lib.KERNEL_TEAM))
@@ -459,7 +544,13 @@ class ShardedTrueKNN:
             try:
                 # (tagged: fixed-capacity messages with the count in their first row -- one exchange, one host round
                 # trip -- once a first exchange at this radius level has told both ends of every pair how much travels)
-                got = comm.exchange_rows(blocks, 4, torch.float32, dev, tag=("halo", level_cap, first))
+                if fixed:
+                    got, went = comm.exchange_fixed(fixed_sel[0], fixed_sel[1], fixed_sel[2], tag, dev, lambda: self._halo_blocks(halo_radius))
+                    for p in range(comm.world):  # what each peer holds of mine now (the straggler rounds send shells)
+                        if p != comm.rank and len(went[p]):
+                            sent[p] = went[p][:, 3].contiguous().view(torch.int32)
+                else:
+                    got = comm.exchange_rows(blocks, 4, torch.float32, dev, tag=tag)
                 got[comm.rank] = got[comm.rank][:0]
                 new_rows = torch.cat(got, dim=0)
                 t = lap("exchange", t)
@@ -510,6 +601,7 @@ class ShardedTrueKNN:
         info["halo_points_by_exchange"] = round_halo  # the first exchange's halo, then the shells of the straggler rounds
         info["halo_levels"] = level_cap
         info["overlapped"] = bool(overlapped)
+        info["halo_select_one_pass"] = bool(one_pass)
         if profile:
             info["phase_ms"] = phase
         self.last = res

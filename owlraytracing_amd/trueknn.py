@@ -118,6 +118,35 @@ class TrueKNN:
                                                     ctypes.c_void_p(rows.data_ptr()), self._stream()))
             return rows, host_counts.tolist()
 
+    def halo_select_fixed(self, boxes, box_peer, npeers, caps):
+        """The one-pass form of ``halo_select`` for the fixed-capacity exchange (tknnHaloSelectFixed): ``caps[p]`` rows per peer.
+        Returns (messages, starts, counts): ``messages`` a (sum(caps) + npeers, 4) float32 buffer in which peer p's message is
+        rows starts[p] .. starts[p] + caps[p] -- a header row (the count, as two float32 cells that hold integers below 2**24
+        exactly) and caps[p] wire rows, those past the count unspecified --, ``counts`` the exact per-peer counts as an int64
+        DEVICE tensor (a count above its capacity: rows were dropped, the caller falls back to ``halo_select``).  Nothing in
+        here waits for the device."""
+        torch = self._torch
+        with torch.cuda.device(self.device):
+            dev = self.device
+            boxes = torch.as_tensor(boxes, dtype=torch.float32, device=dev).contiguous().view(-1, 6)
+            box_peer = torch.as_tensor(box_peer, dtype=torch.int32, device=dev).contiguous()
+            caps = [int(c) for c in caps]
+            starts, at = [], 0
+            for c in caps:
+                starts.append(at)
+                at += c + 1
+            messages = torch.empty((at, 4), dtype=torch.float32, device=dev)
+            caps_dev = torch.tensor(caps, dtype=torch.int64, device=dev)
+            offsets = torch.tensor([s0 + 1 for s0 in starts], dtype=torch.int64, device=dev)
+            counts = torch.empty(npeers, dtype=torch.int64, device=dev)
+            _lib.check(self._lib.tknnHaloSelectFixed(self._h, ctypes.c_void_p(boxes.data_ptr()), ctypes.c_void_p(box_peer.data_ptr()), int(len(box_peer)),
+                                                     int(npeers), ctypes.c_void_p(caps_dev.data_ptr()), ctypes.c_void_p(offsets.data_ptr()),
+                                                     ctypes.c_void_p(messages.data_ptr()), ctypes.c_void_p(counts.data_ptr()), self._stream()))
+            heads = torch.tensor(starts, dtype=torch.int64, device=dev)
+            messages[heads, 0] = (counts % (1 << 24)).float()
+            messages[heads, 1] = (counts >> 24).float()
+            return messages, starts, counts
+
     supports_phases = True  # solve(phase=1 | 2): interior / boundary queries of a tile (tknnSolveOptions.phase)
 
     def solve(self, k, start_radius, kernel=_lib.KERNEL_AUTO, max_rounds=64, want_fb=False,

@@ -166,7 +166,8 @@ def main():
     if rank == 0:
         np.savez(out, gids=gids, idx=idx, dist=dst, isect=isect, rounds=info["rounds"],
                  exchanges=info["halo_exchanges"], halo_points=info["halo_points"], tile=len(solver.points),
-                 halo_by_exchange=np.asarray(info["halo_points_by_exchange"], np.int64), total_isect=info["total_intersections"])
+                 halo_by_exchange=np.asarray(info["halo_points_by_exchange"], np.int64), total_isect=info["total_intersections"],
+                 one_pass=bool(info.get("halo_select_one_pass", False)))
     dist.barrier()
     dist.destroy_process_group()
 

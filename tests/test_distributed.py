@@ -152,6 +152,9 @@ def test_two_ranks_sharing_one_gpu_with_the_hip_engine(tmp_path):
     n, k = 200_000, 10
     got = _run("hip", 2, n, k, "uniform", tmp_path, 29641, {"HALO_LEVELS": "2"})
     _check(got, "uniform", n, k)
+    # the worker solves twice and reports the second solve: its halo rows were selected in ONE pass straight into messages of
+    # the capacity the first exchange taught both ends (tknnHaloSelectFixed), counts read with the headers
+    assert bool(got["one_pass"])
 
 
 @pytest.mark.gpu
@@ -172,6 +175,7 @@ def test_four_ranks_sharing_one_gpu_cross_z_curve_jumps(tmp_path):
     n, k = 400_000, 10
     got = _run("hip", 4, n, k, "uniform", tmp_path, 29651, {"HALO_LEVELS": "2"})
     _check(got, "uniform", n, k)
+    assert bool(got["one_pass"])
     assert int(got["halo_points"]) < int(got["tile"]) // 2
 
 
