@@ -140,7 +140,12 @@ def main():
             r = solver.dbscan(float(os.environ["DBSCAN_EPS"]), int(os.environ.get("DBSCAN_MINPTS", "4")))
         rows = torch.cat([solver.ids.view(-1, 1).double().cpu(), r["labels"].view(-1, 1).double().cpu(),
                           r["core"].view(-1, 1).double().cpu()], dim=1).to(dev)
-        got = torch.cat(solver.comm.exchange_rows([rows for _ in range(world)], 3, torch.float64, dev), dim=0).cpu().numpy()
+        every = int(os.environ.get("GATHER_EVERY", "1"))
+        if every > 1:  # a run at size: the rows of the ids divisible by GATHER_EVERY, to rank 0 only
+            rows = rows[(solver.ids % every == 0).to(rows.device)]
+            got = torch.cat(solver.comm.exchange_rows([rows if p == 0 else rows[:0] for p in range(world)], 3, torch.float64, dev), dim=0).cpu().numpy()
+        else:
+            got = torch.cat(solver.comm.exchange_rows([rows for _ in range(world)], 3, torch.float64, dev), dim=0).cpu().numpy()
         got = got[np.argsort(got[:, 0])]
         print("rank %d tile=%d halo=%d clusters=%d label rounds=%d" % (rank, len(solver.points), r["info"]["halo_points"],
                                                                     r["info"]["clusters"], r["info"]["rounds"]), flush=True)
@@ -162,7 +167,18 @@ def main():
     if use_gpu:
         torch.cuda.synchronize()
     print('rank %d tile=%d halo=%d exchanges=%d solve_s first=%.4f second=%.4f kernel_ms=%.2f' % (rank, len(solver.points), info['halo_points'], info['halo_exchanges'], t1 - t0, time.perf_counter() - t1, info['dominant_kernel_ms']), flush=True)
-    gids, idx, dst, isect = solver.gather_rows()
+    every = int(os.environ.get("GATHER_EVERY", "1"))
+    if every > 1:
+        # a run at size: only the rows of the ids divisible by GATHER_EVERY travel to rank 0 (all of them would be gigabytes)
+        keep = torch.nonzero(solver.ids % every == 0).flatten()
+        rows = torch.cat([solver.ids[keep].view(-1, 1).double(), solver.last["idx"][keep].double(), solver.last["dist"][keep].double(),
+                          solver.last["intersections"][keep].view(-1, 1).double()], dim=1)
+        got = torch.cat(solver.comm.exchange_rows([rows if p == 0 else rows[:0] for p in range(world)], rows.shape[1], torch.float64, dev), dim=0).cpu().numpy()
+        got = got[np.argsort(got[:, 0])]
+        gids, idx, dst, isect = (got[:, 0].astype(np.int64), got[:, 1:1 + k].astype(np.int32), got[:, 1 + k:1 + 2 * k].astype(np.float32),
+                                 got[:, 1 + 2 * k].astype(np.int64))
+    else:
+        gids, idx, dst, isect = solver.gather_rows()
     if rank == 0:
         np.savez(out, gids=gids, idx=idx, dist=dst, isect=isect, rounds=info["rounds"],
                  exchanges=info["halo_exchanges"], halo_points=info["halo_points"], tile=len(solver.points),

@@ -292,3 +292,44 @@ def test_rccl_branch_with_one_rank(tmp_path):
     ref = oracle.dbscan_auto(make_points("clustered", n), eps0, min_pts, max_noise)
     assert int(got["eps_rounds"]) == ref["rounds"] and float(got["eps"]) == ref["eps"] and int(got["noise"]) == ref["noise"]
     assert np.array_equal(got["labels"], ref["labels"]) and np.array_equal(got["core"], ref["core"])
+
+
+@pytest.mark.gpu
+def test_config4_shaped_tiles_at_size(tmp_path):
+    """BASELINE config 4's tiling had only run at <= 400 k points.  Here the counter-based uniform set (what
+    `bench.py --gpus N` loads) at 20 M points is cut into 4 Morton tiles of 5 M -- ranks sharing the one GPU, host-staged
+    messages --, solved twice (the second solve selects its halo in one pass into fixed-capacity messages), and the rows of every
+    97th id are compared with the CPU replay over all 20 M points: indices, distances, intersection counts, rounds."""
+    n, k, every = 20_000_000, 10, 97
+    got = _run("hip", 4, n, k, "counter", tmp_path, 29691, {"HALO_LEVELS": "2", "GATHER_EVERY": str(every)}, timeout=1200)
+    pts = datasets.uniform3d_counter(0, n, seed=0)
+    q = np.arange(0, n, every, dtype=np.int32)
+    ref = oracle.trueknn(pts, k, datasets.start_radius(n, k), query_ids=q)
+    assert np.array_equal(got["gids"], q.astype(np.int64))
+    assert np.array_equal(got["idx"], ref["idx"][q]) and np.array_equal(got["dist"], ref["dist"][q])
+    assert np.array_equal(got["isect"], ref["intersections"][q])
+    assert int(got["rounds"]) == ref["rounds"] and bool(got["one_pass"])
+    assert 0 < int(got["halo_points"]) < int(got["tile"]) // 4
+
+
+@pytest.mark.gpu
+def test_config5_shaped_tiles_at_size(tmp_path):
+    """... and BASELINE config 5's shape: 10 M heavy-tailed 2-D points over 4 tiles, RT-DBSCAN with the auto-grown eps (growth
+    rounds that only count, one clustering, label propagation on clusters over the tiles).  Reference: the SINGLE-GPU engine's
+    tknnDbscanAuto on the whole set in this process -- which tests/test_dbscan.py::test_config5_set_full_size_auto_eps checks
+    against the CPU spec at 50 M points --: rounds, eps, noise count, cluster count, and labels and core flags of every 7th id."""
+    from dist_worker import make_points
+    from owlraytracing_amd.trueknn import TrueKNN
+    n, eps0, min_pts, max_noise, every = 10_000_000, float(np.float32(0.00001)), 4, 0.02, 7
+    got = _run("hip", 4, n, 4, "planar", tmp_path, 29692, {"DBSCAN_EPS": repr(eps0), "DBSCAN_MINPTS": str(min_pts), "DBSCAN_MAX_NOISE": repr(max_noise),
+                                                            "GATHER_EVERY": str(every)}, timeout=1200)
+    eng = TrueKNN()
+    eng.build(make_points("planar", n))
+    ref = eng.dbscan_auto(eps0, min_pts, max_noise)
+    q = np.arange(0, n, every)
+    assert ref["info"]["rounds"] > 1
+    assert int(got["eps_rounds"]) == ref["info"]["rounds"] and float(got["eps"]) == float(np.float32(ref["info"]["eps"]))
+    assert int(got["noise"]) == ref["info"]["noise"] and int(got["clusters"]) == ref["info"]["clusters"]
+    assert np.array_equal(got["gids"], q)
+    assert np.array_equal(got["labels"], ref["labels"].cpu().numpy()[q]) and np.array_equal(got["core"], ref["core"].cpu().numpy().astype(bool)[q])
+    eng.close()
