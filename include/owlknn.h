@@ -153,7 +153,7 @@ typedef struct {
                     3: only the queries an earlier call with allow_unfinished left without a row (d_levels[row] == -1; d_levels
                     required), from level 0 over own + halo tree; rows and levels of the others are kept -- the sharded
                     driver's straggler rounds: the halo has been widened by the shell the next radius level needs.
-                    Team kernels only (k <= 64). */
+                    Team kernels only (TKNN_KERNEL_AUTO / _TEAM; any k up to TKNN_MAX_K). */
   int32_t *d_idx;
   float *d_dist;
   int64_t *d_intersections;
@@ -163,7 +163,7 @@ typedef struct {
                                  there -- a per-query radius schedule (opt-in: the reference has ONE
                                  radius, samples/s01-trueknn/hostCode.cpp:185,325).  Row q is what the reference's loop gives
                                  for q when started at that radius; every value must be finite and > 0.  Team kernels only
-                                 (k <= 64), no halo tree.  info->final_radius then refers to start_radius. */
+                                 (any k up to TKNN_MAX_K), no halo tree.  info->final_radius then refers to start_radius. */
 } tknnSolveOptions;
 TKNN_API int tknnBuildIds(tknnEngine e, const float *d_xyz, const int32_t *d_ids, int64_t n,
                           tknnBuildInfo *info, void *stream);

@@ -534,6 +534,8 @@ void Engine::solve(const SolveArgs &sa, int kernel, tknnSolveInfo *info, hipStre
     // 64 < k <= TKNN_MAX_K: the team walk with the lists in memory, rows final (three-word keys: no tie pass)
     if (kernel != TKNN_KERNEL_AUTO && kernel != TKNN_KERNEL_TEAM)
       throw ArgError{TKNN_E_UNSUPPORTED, "the lane and wave kernels keep their lists in registers: k <= 64 (k up to TKNN_MAX_K: TKNN_KERNEL_AUTO or TKNN_KERNEL_TEAM)"};
+    if (sa.d_start_radii && halo_count() > 0)
+      throw ArgError{TKNN_E_UNSUPPORTED, "tknnSolveEx: per-query start radii and a halo tree do not combine (the halo is exchanged for ONE radius)"};
     if (sa.phase != 0) {
       if (sa.phase == 3) {
         if (!sa.d_levels) throw ArgError{TKNN_E_ARG, "tknnSolveEx: phase 3 (unfinished queries only) needs the d_levels of the call that left them"};

@@ -83,12 +83,12 @@ constexpr int kLdsList = 64 * 4 + 16;  // + the bucket-presence word of the list
 constexpr int kLdsStack = kTeamStack * 4;
 constexpr int kLdsShared = (kLdsCnt + kLdsList) > kLdsStack ? (kLdsCnt + kLdsList) : kLdsStack;
 constexpr int kLdsSharedPadded = (kLdsShared + 15) & ~15;  // the entry lists are read 16 bytes at a time
-// per team (k <= 16): candidates that passed the gate since the last merge into the team's sorted list, as
+// per team (every list size since round 3): candidates that passed the gate since the last merge into the team's sorted list, as
 // 64-bit (dist, index) keys, and how many there are.  At most 16 when a block is tested, so 32 hold any block.
 constexpr int kCandCapacity = 32;
 constexpr int kCandCap = kCandCapacity;
 // LDS per wave, by the number of list registers per lane: query records | block list | per-query block lists |
-// counts, query list / pyramid stack | per-team entry lists | per-team candidate buffers (k <= 16 only)
+// counts, query list / pyramid stack | per-team entry lists | per-team candidate buffers
 template <int NREG>
 struct TeamLayout {
   static constexpr int kMaxPerQuery = max_per_query(NREG);
@@ -802,7 +802,7 @@ __global__ void __launch_bounds__(kTeamBlock) __attribute__((amdgpu_waves_per_eu
   int32_t *qlist = (int32_t *)(base + Lay::kOffShared + kLdsCnt);
   int32_t *stack = (int32_t *)(base + Lay::kOffShared);  // shares the counts / query list region
   int32_t *ent = (int32_t *)(base + Lay::kOffEnt);
-  unsigned long long *cand = (unsigned long long *)(base + Lay::kOffCand);  // (k <= 16 only: zero bytes otherwise, never touched)
+  unsigned long long *cand = (unsigned long long *)(base + Lay::kOffCand);
 
   const LbvhPoint *own_pts = a.bvh.points + tl, *halo_pts = a.halo.points ? a.halo.points + tl : a.bvh.points + tl;
   unsigned long long my_isect_sum = 0, wave_node_tests = 0, wave_point_tests = 0;

@@ -537,6 +537,10 @@ def test_per_query_radius_schedule():
     cases.append(("clustered, radii from the local density", pts, 8, radii.astype(np.float32)))
     lattice = np.stack(np.meshgrid(*[np.arange(14, dtype=np.float32) * np.float32(0.125)] * 3, indexing="ij"), -1).reshape(-1, 3)
     cases.append(("lattice (ties), two classes", lattice, 6, np.where(np.arange(len(lattice)) % 3 == 0, np.float32(0.07), np.float32(0.13)).astype(np.float32)))
+    # ... and above the register lists (k > 64: the team walk with the lists in memory keeps the schedule per query, too)
+    pts = datasets.uniform3d(8_000, seed=43)
+    cases.append(("uniform, k = 70, three classes", pts, 70, rng.choice(np.float32([0.03, 0.06, 0.2]), len(pts))))
+    cases.append(("lattice (ties), k = 80", lattice, 80, np.where(np.arange(len(lattice)) % 3 == 0, np.float32(0.2), np.float32(0.3)).astype(np.float32)))
     for name, pts, k, radii in cases:
         ref = oracle.trueknn_per_query(pts, k, radii)
         eng.build(pts)
