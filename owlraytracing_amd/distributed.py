@@ -95,6 +95,8 @@ class _Comm:
         capacity (both ends see it: the sender by its rows, the receiver by the header), go
         through exact-size messages once more.  Float32 headers hold counts < 2**24 exactly."""
         world, me = self.world, self.rank
+        if world == 1:  # nobody to exchange with (and no count to agree on)
+            return [rows_per_peer[0]]
         if tag is not None and dtype == torch.float32 and (tag, "in") in self._caps:
             cap_in, cap_out = self._caps[(tag, "in")], self._caps[(tag, "out")]
             recv = [None] * world
