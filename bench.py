@@ -657,6 +657,10 @@ def dbscan_rooflines(info, infos, n_local, min_pts):
                 for kk in ("bytes_per_launch", "FETCH_SIZE_KB_per_launch", "WRITE_SIZE_KB_per_launch"):
                     rec[kk] = rec[kk] + rec2[kk]
                 r["kernels_of_the_pass"] = ["db_label_kernel", "db_rows_from_slots_kernel"]
+                r["traffic_note"] = ("most of it is the gather's FETCH_SIZE: one 64-byte fabric request per scattered 4-byte word of a 40 MB array the "
+                                     "launch before has written (served by the 256 MiB Infinity Cache, whose hits the counter includes); the x2 of wide "
+                                     "coalesced reads (MI355X_MICROARCH.md, HBM) is applied to it as to every kernel although that width is uncalibrated: an "
+                                     "upper bound.  Written: 40 MB by slot + 49 MB by row, where the scatter of round 3 wrote 648 MB")
             else:
                 rec, why_not = None, "db_rows_from_slots_kernel: " + str(why2)
         if rec:
