@@ -452,6 +452,41 @@ def test_full_size_properties_c2(kernel):
     eng.close()
 
 
+def test_full_size_c2_set_above_the_register_lists():
+    """BASELINE config 2's point set at k = 100 (the reference takes any k, hostCode.cpp:111): the team walk with the lists in
+    memory over all 10 M queries -- structure of all 10^9 list entries, every distance recomputed in fp64 (in slices), and the
+    rows of every 5 003rd query bit-exact against the CPU replay."""
+    import torch
+    n, k = 10_000_000, 100
+    xyz = datasets.uniform3d(n, seed=0)
+    r0 = datasets.start_radius(n, k)
+    eng = _engine()
+    eng.build(xyz)
+    r = eng.solve(k, r0)
+    idx, dist, isect, info = r["idx"], r["dist"], r["intersections"], r["info"]
+    assert info["unfinished"] == 0 and info["list_capacity"] == 112 and info["tie_rows"] == 0
+    assert int(isect.sum()) == info["total_intersections"]
+    pts = torch.from_numpy(xyz).to(idx.device)
+    worst = 0.0
+    step = 1_000_000
+    for lo in range(0, n, step):
+        i, d = idx[lo:lo + step], dist[lo:lo + step]
+        ar = torch.arange(lo, lo + len(i), device=i.device, dtype=torch.int32)[:, None]
+        assert bool((i != ar).all()) and bool((i >= 0).all()) and bool((i < n).all())
+        assert bool((d[:, 1:] >= d[:, :-1]).all())
+        d64 = (pts[i.long()].double() - pts[lo:lo + len(i), None, :].double()).norm(dim=2)
+        worst = max(worst, float((d64 - d.double()).abs().max()))
+        del d64, ar
+    assert worst < 1e-6
+    q = np.arange(0, n, 5003, dtype=np.int32)
+    ref = oracle.trueknn(xyz, k, r0, query_ids=q)
+    assert info["rounds"] == ref["rounds"]
+    assert np.array_equal(idx[q.astype(np.int64)].cpu().numpy(), ref["idx"][q])
+    assert np.array_equal(dist[q.astype(np.int64)].cpu().numpy(), ref["dist"][q])
+    assert np.array_equal(isect[q.astype(np.int64)].cpu().numpy(), ref["intersections"][q])
+    eng.close()
+
+
 def test_full_size_config4_set_on_one_gpu():
     """BASELINE config 4's point set -- 100 M counter-based uniform points, k = 10 -- on ONE GPU (the run README / DESIGN
     quote a time for; the 8-GPU tiling of the same set is tests/test_distributed.py's business):
