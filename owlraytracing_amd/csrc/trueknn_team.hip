@@ -48,19 +48,46 @@ namespace {
 
 constexpr int kTeamBlock = 64;      // one wave per workgroup: LDS, not the block shape, limits residency
 // leaf blocks one packet may need per level.  A per-query list names them by byte slots: 256 -- except with four list
-// registers per lane (k > 32), where the lists of the last level outgrow that (10 M uniform points at k = 64: 36 % of the queries
+// registers per lane (k > 48), where the lists of the last level outgrow that (10 M uniform points at k = 64: 36 % of the queries
 // were handed to the team walk, two thirds of the solve): 512, the ninth bit of a slot in a word of its own
-// (96 bits per query)
-constexpr int max_blocks(int nreg) { return nreg == 4 ? 512 : 256; }
+// (four words per query)
+#ifndef TKNN_MAX_BLOCKS_3
+#define TKNN_MAX_BLOCKS_3 256
+#endif
+#ifndef TKNN_MAX_BLOCKS_4
+#define TKNN_MAX_BLOCKS_4 512
+#endif
+constexpr int max_blocks(int nreg) { return nreg == 4 ? TKNN_MAX_BLOCKS_4 : (nreg == 3 ? TKNN_MAX_BLOCKS_3 : 256); }
 #ifndef TKNN_MAX_PER_QUERY
 #define TKNN_MAX_PER_QUERY 72  // (k <= 16)
 #endif
-// leaf blocks one query may need per level: k <= 16 (one list register per lane) 72 -- lists of the benchmark run to 60 --,
-// k <= 32 96 (a third of the queries of 10 M uniform points need more than 72 at k = 32 and would be handed over), k > 32 124
-#ifndef TKNN_MAX_PER_QUERY_4
-#define TKNN_MAX_PER_QUERY_4 124  // (k > 32; round 4: with 512 blocks per packet the queries' own lists were what handed over)
+// leaf blocks one query may need per level, by the number of list registers per lane (k <= 16 / 32 / 48 / 64).  The timings step
+// as if LDS were allocated in granules of 1 280 bytes, 128 of them per CU, so the sizes are chosen by that granule:
+//   1: 72 slots (lists of the benchmark run to 60)             10 192 bytes = 8 granules, 16 waves per CU (the register limit)
+//   2, 3: 88 slots                                             11 472 bytes = 9 granules, 14 waves
+//         (round 4; 96 slots = 10 granules = 12 waves cost 10 % at k = 17 .. 44 on uniform, mixture and taxi-like sets of
+//         10 M points; 72 would hand over a third of the queries of the uniform set at k = 32, 88 none)
+//   4: 124 slots and 512 blocks per packet                     16 400 bytes = 13 granules, 9 waves
+//         (round 4: with 256 blocks and 96 slots 36 % of the queries of 10 M uniform points were handed over at k = 64;
+//         116 slots and 384 blocks = 12 granules = 10 waves: the packet kernel 8 % faster, the hand-overs eat it)
+#ifndef TKNN_MAX_PER_QUERY_2
+#define TKNN_MAX_PER_QUERY_2 88
 #endif
-constexpr int max_per_query(int nreg) { return nreg == 1 ? TKNN_MAX_PER_QUERY : (nreg == 4 ? TKNN_MAX_PER_QUERY_4 : 96); }
+#ifndef TKNN_MAX_PER_QUERY_3
+#define TKNN_MAX_PER_QUERY_3 88
+#endif
+#ifndef TKNN_MAX_PER_QUERY_4
+#define TKNN_MAX_PER_QUERY_4 124
+#endif
+constexpr int max_per_query(int nreg) {
+  return nreg == 1 ? TKNN_MAX_PER_QUERY : (nreg == 4 ? TKNN_MAX_PER_QUERY_4 : (nreg == 3 ? TKNN_MAX_PER_QUERY_3 : TKNN_MAX_PER_QUERY_2));
+}
+// list registers per lane for k: 16 entries each.  Three (k = 33 .. 48; round 4) spare those k the four-register
+// instantiation's fourth merge step and its 13 granules of LDS (10 M uniform points: 22.2 -> 15.0 ms at k = 33, 14.2 -> 12.7 at k = 32)
+#ifndef TKNN_NREG3
+#define TKNN_NREG3 1
+#endif
+inline int nreg_for(int k) { return k <= 16 ? 1 : (k <= 32 ? 2 : (k <= 48 && TKNN_NREG3 ? 3 : 4)); }
 #ifndef TKNN_MERGE_AT
 #define TKNN_MERGE_AT 12  // buffered candidates of some team at the end of a group of four blocks that trigger a merge
 #endif
@@ -1152,7 +1179,7 @@ __global__ void __launch_bounds__(kTeamBlock) __attribute__((amdgpu_waves_per_eu
       // the rest carry on -- 0.49 M instead of 2.3 M of 10 M uniform points at k = 50.  (For k <= 32
       // that finer hand-over changed little on the clustered sets and cost 1 % on the benchmark: the
       // loop no longer ends at this point, which moved the register allocation.)
-      if (NREG < 4) {
+      if (NREG < 3) {
         if (__ballot(my_nblk > kMaxPerQuery) != 0ull) too_big = true;
         if (too_big) {
           if (active) {
@@ -2293,9 +2320,9 @@ void Engine::launch_tie_fix(const SolveArgs &sa, const int32_t *slots, int32_t n
   a.slot_count = d_slot_count;
   a.counters = counters_;
   using FixEntry = void (*)(TeamArgs, const int32_t *, int32_t);
-  static const FixEntry entries[2][3] = {{tie_fix_kernel<false, 1>, tie_fix_kernel<false, 2>, tie_fix_kernel<false, 4>},
-                                         {tie_fix_kernel<true, 1>, tie_fix_kernel<true, 2>, tie_fix_kernel<true, 4>}};
-  const FixEntry entry = entries[halo_count() > 0 ? 1 : 0][sa.k <= 16 ? 0 : (sa.k <= 32 ? 1 : 2)];
+  static const FixEntry entries[2][4] = {{tie_fix_kernel<false, 1>, tie_fix_kernel<false, 2>, tie_fix_kernel<false, 3>, tie_fix_kernel<false, 4>},
+                                         {tie_fix_kernel<true, 1>, tie_fix_kernel<true, 2>, tie_fix_kernel<true, 3>, tie_fix_kernel<true, 4>}};
+  const FixEntry entry = entries[halo_count() > 0 ? 1 : 0][nreg_for(sa.k) - 1];
   void *kargs[] = {(void *)&a, (void *)&slots, (void *)&nslots};
   OWLMI_HIP(hipLaunchKernel((const void *)entry, dim3(blocks), dim3(kTeamBlock), kargs, 0, s));
 }
@@ -2438,12 +2465,11 @@ bool Engine::solve_team(const SolveArgs &sa, tknnSolveInfo *info, hipStream_t s)
   hipDeviceProp_t prop;
   OWLMI_HIP(hipGetDeviceProperties(&prop, device_));
   int per_cu = 2;
-  const int nreg_for_lds = sa.k <= 16 ? 1 : (sa.k <= 32 ? 2 : 4);
-  const size_t lds = (size_t)kTeamBlock / 64 *
-                     (size_t)(nreg_for_lds == 1 ? TeamLayout<1>::kTeamLds : (nreg_for_lds == 2 ? TeamLayout<2>::kTeamLds : TeamLayout<4>::kTeamLds));
+  const int nreg = nreg_for(sa.k);  // list registers per lane
+  const size_t lds = (size_t)kTeamBlock / 64 * (size_t)(nreg == 1 ? TeamLayout<1>::kTeamLds : (nreg == 2 ? TeamLayout<2>::kTeamLds
+                                                         : (nreg == 3 ? TeamLayout<3>::kTeamLds : TeamLayout<4>::kTeamLds)));
   const bool with_halo = halo_count() > 0;
-  const int nreg = sa.k <= 16 ? 1 : (sa.k <= 32 ? 2 : 4);  // list registers per lane
-  const int nreg_at = nreg == 4 ? 2 : nreg - 1;           // index into the tables of instantiations
+  const int nreg_at = nreg - 1;  // index into the tables of instantiations
   const char *walk_all = getenv("TKNN_TEAM_WALK_ALL");    // measurements only: k > 32 without the packet kernel
   if (sa.k > 32 && walk_all && atoi(walk_all)) {
     // (33 <= k <= 64 as it was before the packet kernel had four list registers per lane:) every
@@ -2500,11 +2526,11 @@ bool Engine::solve_team(const SolveArgs &sa, tknnSolveInfo *info, hipStream_t s)
   }
   const bool full_list = sa.k == 16 * nreg;  // no spare list entry to see a tie with the row's last in
   using TeamEntry = void (*)(TeamArgs);
-  static const TeamEntry entries[2][3][2] = {
+  static const TeamEntry entries[2][4][2] = {
       {{team_kernel<false, 1, false>, team_kernel<false, 1, true>}, {team_kernel<false, 2, false>, team_kernel<false, 2, true>},
-       {team_kernel<false, 4, false>, team_kernel<false, 4, true>}},
+       {team_kernel<false, 3, false>, team_kernel<false, 3, true>}, {team_kernel<false, 4, false>, team_kernel<false, 4, true>}},
       {{team_kernel<true, 1, false>, team_kernel<true, 1, true>}, {team_kernel<true, 2, false>, team_kernel<true, 2, true>},
-       {team_kernel<true, 4, false>, team_kernel<true, 4, true>}}};
+       {team_kernel<true, 3, false>, team_kernel<true, 3, true>}, {team_kernel<true, 4, false>, team_kernel<true, 4, true>}}};
   const TeamEntry entry = entries[with_halo ? 1 : 0][nreg_at][full_list ? 1 : 0];
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)entry, kTeamBlock, lds) != hipSuccess) per_cu = 2;
   per_cu = std::max(1, per_cu);
@@ -2637,8 +2663,8 @@ bool Engine::solve_team(const SolveArgs &sa, tknnSolveInfo *info, hipStream_t s)
       OWLMI_HIP(hipEventRecord(ev_a_, s));
       {
         using WalkEntry = void (*)(TeamArgs, const int32_t *, int32_t);
-        static const WalkEntry walks[2][3] = {{team_walk_kernel<false, 1>, team_walk_kernel<false, 2>, team_walk_kernel<false, 4>},
-                                              {team_walk_kernel<true, 1>, team_walk_kernel<true, 2>, team_walk_kernel<true, 4>}};
+        static const WalkEntry walks[2][4] = {{team_walk_kernel<false, 1>, team_walk_kernel<false, 2>, team_walk_kernel<false, 3>, team_walk_kernel<false, 4>},
+                                              {team_walk_kernel<true, 1>, team_walk_kernel<true, 2>, team_walk_kernel<true, 3>, team_walk_kernel<true, 4>}};
         const int32_t *slots = slot_list_;
         int32_t nslots = (int32_t)handed;
         void *kargs[] = {(void *)&a, (void *)&slots, (void *)&nslots};

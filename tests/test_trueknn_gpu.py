@@ -61,7 +61,7 @@ def test_golden_vectors(golden, kernel):
 
 @pytest.mark.parametrize("kernel", KERNELS, ids=KERNEL_IDS)
 @pytest.mark.parametrize("n,k,seed", [(100_000, 5, 0), (50_000, 10, 1), (30_000, 16, 2), (20_000, 3, 3),
-                                      (30_000, 17, 4), (40_000, 24, 5), (25_000, 32, 6), (25_000, 33, 7), (20_000, 50, 8),
+                                      (30_000, 17, 4), (40_000, 24, 5), (25_000, 32, 6), (25_000, 33, 7), (22_000, 40, 14), (20_000, 48, 15), (20_000, 49, 16), (20_000, 50, 8),
                                       (20_000, 64, 9), (12_000, 65, 10), (10_000, 100, 11), (6_000, 256, 12), (5_000, 1024, 13)])
 def test_against_oracle_uniform(kernel, n, k, seed):
     xyz = datasets.uniform3d(n, seed=seed)
@@ -155,7 +155,7 @@ def test_points_with_nan_coordinates_are_nobodys_candidates(kernel):
 
 
 @pytest.mark.parametrize("tail", ["walk", "lane", "wave"])
-@pytest.mark.parametrize("k", [7, 24])
+@pytest.mark.parametrize("k", [7, 24, 40])
 def test_team_kernel_tails_agree_when_everything_is_handed_over(monkeypatch, tail, k):
     """A start radius far too large for the density of the cluster cores: nearly every packet outgrows the team kernel's LDS lists
     at level 0, so the rows come from its tail -- the team walk (one query per team, subtrees counted),
@@ -239,11 +239,11 @@ _TIE_SETS = {}
 
 @pytest.mark.parametrize("kernel", KERNELS, ids=KERNEL_IDS)
 @pytest.mark.parametrize("tail", [None, "walk", "lane"])
-@pytest.mark.parametrize("k", [1, 5, 16, 17, 32, 33, 64, 65, 100])
+@pytest.mark.parametrize("k", [1, 5, 16, 17, 32, 33, 48, 64, 65, 100])
 def test_tie_heavy_sets_equal_the_replay(kernel, tail, k, monkeypatch):
     """Lattices with holes and coarsely quantised coordinates: almost every row has bit-identical
     distances inside it or at its end, many of them between candidates of different rounds.  k = 16,
-    32, 64 fill a team's list to the last entry (the tie with the best candidate left out is then
+    32, 48, 64 fill a team's list to the last entry (the tie with the best candidate left out is then
     seen by what leaves the list, not by a spare entry)."""
     if tail and kernel != _lib.KERNEL_TEAM:
         pytest.skip("tails belong to the team kernel")
