@@ -97,6 +97,26 @@ inline int nreg_for(int k) { return k <= 16 ? 1 : (k <= 32 ? 2 : (k <= 48 && TKN
 #ifndef TKNN_TEAM_WAVES
 #define TKNN_TEAM_WAVES 4  // waves per SIMD the packet kernel's register allocation aims at
 #endif
+#ifndef TKNN_WALK_WAVES
+// waves per SIMD the walks' register allocation aims at (0: the compiler's choice, 3 with 131 .. 147 registers).  Round 4: 4 --
+// a few words of scratch outside the loops; 10 M points: the hand-over walk 12 .. 18 % faster (taxi-like set at k = 10: 4.4 -> 3.9 ms,
+// uniform at k = 48: 5.3 -> 4.4 ms), the k > 64 walk 17 % (k = 65: 209 -> 174 ms); 5 and 6 spill inside the loops and lose
+#define TKNN_WALK_WAVES 4
+#endif
+#if TKNN_WALK_WAVES
+#define TKNN_WALK_ATTR __attribute__((amdgpu_waves_per_eu(TKNN_WALK_WAVES)))
+#else
+#define TKNN_WALK_ATTR
+#endif
+#ifndef TKNN_BIGK_WAVES
+#define TKNN_BIGK_WAVES 4
+#endif
+#if TKNN_BIGK_WAVES
+#define TKNN_BIGK_ATTR __attribute__((amdgpu_waves_per_eu(TKNN_BIGK_WAVES)))
+#else
+#define TKNN_BIGK_ATTR
+#endif
+constexpr int kWalkBlocksPerCu = 4 * (TKNN_WALK_WAVES > 4 ? TKNN_WALK_WAVES : 4);  // one-wave workgroups of the walks' launches
 constexpr int kTeamStack = 192;     // wide-pyramid stack entries per wave
 constexpr int kQrecStride = 6;      // floats per LDS query record (layout below)
 constexpr int kScanBudget = 16384;  // leaf blocks one packet-level may test against its queries before it is handed over
@@ -1381,7 +1401,7 @@ struct WalkLevel {  // per tree and pyramid level, in LDS: lanes of different te
 };
 
 template <bool HALO, int NREG>
-__global__ void __launch_bounds__(kTeamBlock) team_walk_kernel(TeamArgs a, const int32_t *slots, int32_t nslots) {
+__global__ void __launch_bounds__(kTeamBlock) TKNN_WALK_ATTR team_walk_kernel(TeamArgs a, const int32_t *slots, int32_t nslots) {
   __shared__ int32_t stack_mem[4 * kWalkStack];
   __shared__ WalkLevel levels[2][LBVH_WIDE_LEVELS];
   __shared__ unsigned long long cand_mem[4 * kCandCapacity];  // per team: candidates waiting to be merged into its list (t_merge_rows)
@@ -1925,7 +1945,7 @@ __device__ __forceinline__ void t_clean16_3(uint32_t &kd, uint32_t &kl, uint32_t
 #undef T_EX3
 
 template <bool HALO>
-__global__ void __launch_bounds__(kTeamBlock) bigk_walk_kernel(TeamArgs a, BigKey *lists, int chunks) {
+__global__ void __launch_bounds__(kTeamBlock) TKNN_BIGK_ATTR bigk_walk_kernel(TeamArgs a, BigKey *lists, int chunks) {
   __shared__ int32_t stack_mem[4 * kWalkStack];
   __shared__ WalkLevel levels[2][LBVH_WIDE_LEVELS];
   __shared__ BigKey cand_mem[4 * kCandCapacity];     // per team: candidates waiting to be merged, (squared distance, first level, index)
@@ -2480,7 +2500,7 @@ bool Engine::solve_team(const SolveArgs &sa, tknnSolveInfo *info, hipStream_t s)
     OWLMI_HIP(hipMemsetAsync(isect_sorted_, 0, (size_t)n * sizeof(int64_t), s));
     OWLMI_HIP(hipMemsetAsync(next_level_, 0, (size_t)n * sizeof(int32_t), s));
     if (sa.d_levels) OWLMI_HIP(hipMemsetAsync(sa.d_levels, 0xff, (size_t)n * sizeof(int32_t), s));
-    const int walk_blocks = (int)std::min<int64_t>((n + 3) / 4, (int64_t)prop.multiProcessorCount * 16);
+    const int walk_blocks = (int)std::min<int64_t>((n + 3) / 4, (int64_t)prop.multiProcessorCount * kWalkBlocksPerCu);
     OWLMI_HIP(hipEventRecord(ev_a_, s));
     if (with_halo)
       hipLaunchKernelGGL((team_walk_kernel<true, 4>), dim3(walk_blocks), dim3(kTeamBlock), 0, s, a, (const int32_t *)nullptr, (int32_t)n);
@@ -2659,7 +2679,7 @@ bool Engine::solve_team(const SolveArgs &sa, tknnSolveInfo *info, hipStream_t s)
       }
       OWLMI_HIP(hipcub::DeviceSelect::Flagged(wave_ws_, tmp_bytes, iota, flags, slot_list_, d_count, (int)n, s));
       OWLMI_HIP(hipMemsetAsync(counters_, 0, 16 * sizeof(unsigned long long), s));
-      const int walk_blocks = (int)std::min<int64_t>((int64_t)(handed + 3) / 4, (int64_t)prop.multiProcessorCount * 16);
+      const int walk_blocks = (int)std::min<int64_t>((int64_t)(handed + 3) / 4, (int64_t)prop.multiProcessorCount * kWalkBlocksPerCu);
       OWLMI_HIP(hipEventRecord(ev_a_, s));
       {
         using WalkEntry = void (*)(TeamArgs, const int32_t *, int32_t);

@@ -26,7 +26,9 @@ eng.build(pts)
 for k in ks:
     r0 = r_fixed or datasets.start_radius(n, k)
     best = None
+    r = None
     for _ in range(2):
+        r = None
         torch.cuda.synchronize()
         t = time.perf_counter()
         r = eng.solve(k, r0, kernel=3)
