@@ -56,7 +56,7 @@ def main():
             n = min(n, 20_000)
         name, xyz = make(rng, n)
         n = len(xyz)
-        k = int(rng.choice([65, 80, 100, 160, 300])) if big_k else int(rng.choice([1, 2, 3, 5, 8, 10, 16, 17, 24, 32, 33, 48, 64]))
+        k = int(rng.choice([65, 80, 100, 160, 300])) if big_k else int(rng.choice([1, 2, 3, 5, 8, 10, 16, 17, 24, 32, 33, 40, 47, 48, 49, 64]))
         kernels = (_lib.KERNEL_TEAM, _lib.KERNEL_WAVE, _lib.KERNEL_LANE) if k <= 64 else (_lib.KERNEL_TEAM,)  # (k > 64: the lists in memory, team walk only)
         if n <= k + 1:
             continue
