@@ -61,8 +61,8 @@ constexpr int max_blocks(int nreg) { return nreg == 4 ? TKNN_MAX_BLOCKS_4 : (nre
 #ifndef TKNN_MAX_PER_QUERY
 #define TKNN_MAX_PER_QUERY 72  // (k <= 16)
 #endif
-// leaf blocks one query may need per level, by the number of list registers per lane (k <= 16 / 32 / 48 / 64).  The timings step
-// as if LDS were allocated in granules of 1 280 bytes, 128 of them per CU, so the sizes are chosen by that granule:
+// leaf blocks one query may need per level, by the number of list registers per lane (k <= 16 / 32 / 48 / 64).  LDS is
+// allocated in granules of 1 280 bytes, 128 of them per CU (lds_workgroups_per_cu below), so the sizes are chosen by the granule:
 //   1: 72 slots (lists of the benchmark run to 60)             10 192 bytes = 8 granules, 16 waves per CU (the register limit)
 //   2, 3: 88 slots                                             11 472 bytes = 9 granules, 14 waves
 //         (round 4; 96 slots = 10 granules = 12 waves cost 10 % at k = 17 .. 44 on uniform, mixture and taxi-like sets of
@@ -81,6 +81,13 @@ constexpr int max_blocks(int nreg) { return nreg == 4 ? TKNN_MAX_BLOCKS_4 : (nre
 #endif
 constexpr int max_per_query(int nreg) {
   return nreg == 1 ? TKNN_MAX_PER_QUERY : (nreg == 4 ? TKNN_MAX_PER_QUERY_4 : (nreg == 3 ? TKNN_MAX_PER_QUERY_3 : TKNN_MAX_PER_QUERY_2));
+}
+// One-wave workgroups of `lds` bytes a CU holds at once: LDS is allocated in granules of 1 280 bytes (measured:
+// scripts/microbench/lds_granule.hip, profiles/r04_lds_granule.txt -- the residency of a launch steps at every multiple of 1 280
+// bytes, hipOccupancyMaxActiveBlocksPerMultiprocessor divides by the byte and says 13 where 12 fit)
+inline int lds_workgroups_per_cu(size_t lds) {
+  const size_t granule = 1280, total = 160 * 1024;  // gfx950
+  return lds ? (int)((total / granule) / ((lds + granule - 1) / granule)) : 1 << 20;
 }
 // list registers per lane for k: 16 entries each.  Three (k = 33 .. 48; round 4) spare those k the four-register
 // instantiation's fourth merge step and its 13 granules of LDS (10 M uniform points: 22.2 -> 15.0 ms at k = 33, 14.2 -> 12.7 at k = 32)
@@ -2553,7 +2560,9 @@ bool Engine::solve_team(const SolveArgs &sa, tknnSolveInfo *info, hipStream_t s)
        {team_kernel<true, 3, false>, team_kernel<true, 3, true>}, {team_kernel<true, 4, false>, team_kernel<true, 4, true>}}};
   const TeamEntry entry = entries[with_halo ? 1 : 0][nreg_at][full_list ? 1 : 0];
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)entry, kTeamBlock, lds) != hipSuccess) per_cu = 2;
-  per_cu = std::max(1, per_cu);
+  // (the query divides the CU's LDS by the byte; the hardware hands it out in granules: scripts/microbench/lds_granule.hip --
+  // a launch of more workgroups than fit would leave the surplus waiting for a slot and then for the last packets)
+  per_cu = std::max(1, std::min(per_cu, lds_workgroups_per_cu(lds)));
   if (const char *cap = getenv("TKNN_TEAM_WAVES_PER_CU"))  // measurements only: how the packet kernel's time scales with the waves in flight
     per_cu = std::max(1, std::min(per_cu, atoi(cap)));
   const int64_t want = (a.ngroups + kTeamBlock / 64 - 1) / (kTeamBlock / 64);
