@@ -114,7 +114,7 @@ TKNN_API int tknnBuild(tknnEngine e, const float *d_xyz, int64_t n, tknnBuildInf
 
 /* Solve TrueKNN for every point (queries = points, deviceCode.cu:140-153).
  *   k, start_radius   as argv[5], argv[4] of the sample; n > k and 0 < start_radius < inf required
- *   max_rounds        give up (TKNN_E_ROUNDS) after this many radius levels; <= 0 means 64
+ *   max_rounds        give up (TKNN_E_ROUNDS) after this many radius levels; <= 0 means 64, more than 127 means 127
  *   d_idx, d_dist     n*k each, row q = neighbours of point q (caller's index), ascending
  *                     (dist, index); either may be NULL
  *   d_intersections   n, Neigh.intersections of slot 0 of each row; may be NULL

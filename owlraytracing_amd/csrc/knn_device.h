@@ -43,15 +43,20 @@ __device__ __forceinline__ int32_t knn_key_prim(uint64_t key) {
 
 // Rows whose order depends on how bit-identical distances are ordered (KList::has_ties below) are
 // flagged by whichever kernel finishes them and redone by tie_fix_kernel (trueknn_team.hip):
-// tie[slot] = 1 + the level the query finished at, counters[kTieCounter] counts them, and the first
+// tie[slot] = 1 + the level the query finished at (bit 7: see `edge` below), counters[kTieCounter] counts them, and the first
 // kTieListCap slots are also listed so that the usual handful needs no compaction pass.
-// counters[kTieCounter + 1]: tie_fix_kernel's work cursor, [kTieCounter + 2]: rows it had to leave.
+// counters[kTieCounter + 1]: tie_fix_kernel's work cursor, [kTieCounter + 2]: rows it had to leave, [kTieCounter + 3]: rows that
+// stood after a look at what is written (see knn_flag_tie).
 constexpr int kTieCounter = 32;  // no kernel's own counter reset reaches this far
 constexpr int kCounters = 40;
 constexpr int kTieListCap = 4096;
-__device__ __forceinline__ void knn_flag_tie(uint8_t *tie, int32_t *tie_list, unsigned long long *counters, int32_t slot, int level) {
-  if (level >= 255) return;
-  tie[slot] = (uint8_t)(1 + level);
+// edge: one of the tied candidates may be the best one LEFT OUT of the row (or the kernel cannot tell): only a walk finds it.
+// Without it every tie lies between two written entries, and tie_fix_kernel first looks whether the pairs' candidates became
+// candidates at the same level (coincident points -- duplicates of a data set -- always do): then the row stands as it is.
+__device__ __forceinline__ void knn_flag_tie(uint8_t *tie, int32_t *tie_list, unsigned long long *counters, int32_t slot, int level,
+                                             bool edge = true) {
+  if (level >= 127) return;  // (tknnSolve caps max_rounds at 127)
+  tie[slot] = (uint8_t)((1 + level) | (edge ? 0x80 : 0));
   const unsigned long long pos = atomicAdd(&counters[kTieCounter], 1ull);
   if (pos < (unsigned long long)kTieListCap) tie_list[pos] = slot;
 }

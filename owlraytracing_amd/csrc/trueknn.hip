@@ -30,7 +30,7 @@ struct LaneRoundArgs {
   float radius;
   int k;
   uint8_t *done;           // per sorted slot
-  uint8_t *tie;            // per sorted slot: 1 + level for rows finished with exact-distance ties (knn_flag_tie)
+  uint8_t *tie;            // per sorted slot: (1 + level) | 0x80 for rows finished with exact-distance ties (knn_flag_tie)
   int32_t *tie_list;
   const int32_t *next_level;  // per sorted slot: first level this query takes part in (may be null)
   int64_t *isect_sorted;   // per sorted slot, accumulated over rounds
@@ -788,7 +788,7 @@ int tknnSolveEx(tknnEngine e, const tknnSolveOptions *options, tknnSolveInfo *in
     owlmi::SolveArgs sa;
     sa.k = k;
     sa.start_radius = start_radius;
-    sa.max_rounds = max_rounds > 0 ? max_rounds : 64;
+    sa.max_rounds = max_rounds > 0 ? std::min(max_rounds, 127) : 64;  // (127: more doublings than fp32 has binades for a radius; the tie flags keep the level in seven bits)
     sa.d_idx = d_idx;
     sa.d_dist = d_dist;
     sa.d_isect = d_intersections;

@@ -88,7 +88,7 @@ class Engine {
   // trueknn_team.hip: redo the rows flagged in tie_ with the reference's order of exact-distance ties
   void fix_ties(const SolveArgs &sa, tknnSolveInfo *info, hipStream_t s);
   void launch_tie_fix(const SolveArgs &sa, const int32_t *slots, int32_t nslots, int blocks, hipStream_t s,
-                      const int32_t *d_slot_count = nullptr);
+                      const int32_t *d_slot_count = nullptr, int64_t expected_rows = 0);
   int first_step_estimate(const SolveArgs &sa) const;
   float scene_[6] = {0, 0, 0, 0, 0, 0};  // bounds of the built point set (host copy)
 

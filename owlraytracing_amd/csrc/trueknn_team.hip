@@ -89,6 +89,12 @@ inline int lds_workgroups_per_cu(size_t lds) {
   const size_t granule = 1280, total = 160 * 1024;  // gfx950
   return lds ? (int)((total / granule) / ((lds + granule - 1) / granule)) : 1 << 20;
 }
+// slots (in fours) a wave takes per turn at the tie pass's work cursor (TeamArgs::grab): so many that a wave comes `turns` times in
+// all, at most `cap`; TKNN_GRAB overrides (measurements)
+inline int grab_for(int64_t count, int blocks, int turns, int cap) {
+  if (const char *g = getenv("TKNN_GRAB")) return std::max(1, atoi(g));
+  return (int)std::max<int64_t>(1, std::min<int64_t>(cap, count / ((int64_t)std::max(1, blocks) * 4 * turns)));
+}
 // list registers per lane for k: 16 entries each.  Three (k = 33 .. 48; round 4) spare those k the four-register
 // instantiation's fourth merge step and its 13 granules of LDS (10 M uniform points: 22.2 -> 15.0 ms at k = 33, 14.2 -> 12.7 at k = 32)
 #ifndef TKNN_NREG3
@@ -204,13 +210,19 @@ struct TeamArgs {
   uint8_t *done;
   int64_t *isect_sorted;
   int32_t *next_level;
-  // per sorted slot: 1 + level for rows that finished with bit-identical distances among entries 0..k of
-  // the list (entry k: the best candidate left out); tie_fix_kernel redoes them in the reference's tie order
+  // per sorted slot: 1 + level (| 0x80: knn_flag_tie's `edge`) for rows that finished with bit-identical distances among entries
+  // 0..k of the list (entry k: the best candidate left out); tie_fix_kernel redoes them in the reference's tie order
   uint8_t *tie;
   int32_t *tie_list;
   const uint8_t *skip;  // per sorted slot, or null: queries with skip[slot] == skip_is sit this solve out (tknnSolveOptions.phase)
   int32_t skip_is;
   const int32_t *slot_count;  // tie_fix_kernel, nslots == -2: length of `slots` as hipCUB's select wrote it (device side)
+  // a wave takes 4 * grab consecutive slots per turn at the work cursor (>= 1).  One address, device scope: a turn costs some
+  // 12 ns whoever asks -- at four rows a turn that was ALL of the tie pass on duplicate-heavy sets (10 M taxi-like points, k = 10 / 24:
+  // 0.78 / 2.3 M rows in 2.5 / 7.2 ms; with longer turns 1.1 / 2.8 ms).  The walks keep 1: their queries differ too much in cost
+  // (turns of up to 64 slots: the hand-over walk 4.0 -> 4.5 ms on that set, the k = 65 walk 173 -> 189 ms on 10 M uniform points).
+  int grab;
+  const int32_t *row_slot;    // tie_fix_kernel: the sorted slot of row i (Lbvh::row_slot_device), or null: no look at the written row first
   // [0] (unused here) [16..23] per-XCD packet counters [1] max levels [2] node tests [3] point tests [4] sum isect
   // [5] error flags (1 max_rounds) [6] sum levels [7] unfinished [8] handed over [9] min hand-over level
   unsigned long long *counters;
@@ -775,11 +787,11 @@ __device__ __forceinline__ void team_pass(const TeamArgs &a, const TeamLds &L, i
     const uint32_t self = cnt ? 1u : 0u;  // a query lies in its own box, and ids are unique
     const uint32_t others = cnt - self;
     if (TWO) cnt_i0 = t_team_sum(cnt_i0);
-    uint32_t tied = 0u;
+    uint32_t tied = 0u;  // bit 0: the row has ties that may span two rounds, bit 1: ... one of them with the best candidate left out
     if (SELECT) {
       // entry j against entry j - 1, for j = 1..k (KList::has_ties is the per-lane form of this)
       bool tie[NREG];
-      bool any = false;
+      bool any = false, edge = false;
 #pragma unroll
       for (int j = 0; j < NREG; j++) {
         uint32_t before = t_team_shr1(bd[j]);
@@ -793,16 +805,21 @@ __device__ __forceinline__ void team_pass(const TeamArgs &a, const TeamLds &L, i
         any = false;
         const float q_r0 = a.start_radii ? a.start_radii[a.bvh.prim_id[first_slot + qi]] : a.start_radius;
 #pragma unroll
-        for (int j = 0; j < NREG; j++) any |= tie[j] && tie_may_straddle(__uint_as_float(bd[j]), q_r0, t_r, qmax, a.tie_span);
+        for (int j = 0; j < NREG; j++) {
+          const bool t = tie[j] && tie_may_straddle(__uint_as_float(bd[j]), q_r0, t_r, qmax, a.tie_span);
+          any |= t;
+          // ... with a candidate that is not written: entry k of a list with room to spare, the best one left out of a full list
+          edge |= t && (16 * j + tl == a.k || (full && j == NREG - 1 && tl == 15 && left_out == bd[j]));
+        }
       }
-      tied = ((uint32_t)(__ballot(any) >> (team * 16)) & 0xffffu) ? 1u : 0u;
+      tied = (((uint32_t)(__ballot(any) >> (team * 16)) & 0xffffu) ? 1u : 0u) | (((uint32_t)(__ballot(edge) >> (team * 16)) & 0xffffu) ? 2u : 0u);
     }
     if (on && tl == 0) {
       // counts innermost level first; a one-level pass fills slot 0
       uint32_t *out = L.qcnt + qi * 2;
       if (!TWO) {
         out[0] = cnt;
-        out[1] = (self << 31) | (tied << 30);
+        out[1] = (self << 31) | ((tied & 1u) << 30) | ((tied >> 1) << 29);
       } else {
         out[0] = cnt_i0;
         out[1] = cnt | (self << 31);
@@ -1332,7 +1349,8 @@ __global__ void __launch_bounds__(kTeamBlock) __attribute__((amdgpu_waves_per_eu
         if (a.out_fb) a.out_fb[(int64_t)row * a.k].intersections = isect;
         const int fin_level = level + (fin_at > 0 ? fin_at : 0);
         if (a.out_level) a.out_level[row] = fin_level;
-        if ((qcnt[lane * 2 + 1] >> 30) & 1u) knn_flag_tie(a.tie, a.tie_list, a.counters, slot, fin_level);  // SELECT saw exact-distance ties
+        if ((qcnt[lane * 2 + 1] >> 30) & 1u)  // SELECT saw exact-distance ties
+          knn_flag_tie(a.tie, a.tie_list, a.counters, slot, fin_level, ((qcnt[lane * 2 + 1] >> 29) & 1u) != 0u);
       }
       active = active && !finished;
       level += m;
@@ -1423,10 +1441,17 @@ __global__ void __launch_bounds__(kTeamBlock) TKNN_WALK_ATTR team_walk_kernel(Te
   unsigned long long isect_sum = 0, levels_sum = 0, node_tests = 0, point_tests = 0;
   unsigned int unfinished = 0, failed = 0;
   int max_level = 0;
+  int turn_next = 0, turn_left = 0;  // wave-uniform: the slots of my turn at the cursor that are still to do
   for (;;) {
-    int base = 0;
-    if (lane == 0) base = (int)atomicAdd(&a.counters[0], 4ull);
-    base = __builtin_amdgcn_readfirstlane(base);
+    if (turn_left == 0) {
+      int got = 0;
+      if (lane == 0) got = (int)atomicAdd(&a.counters[0], 4ull * (unsigned long long)max(a.grab, 1));
+      turn_next = __builtin_amdgcn_readfirstlane(got);
+      turn_left = max(a.grab, 1);
+    }
+    const int base = turn_next;
+    turn_next += 4;
+    turn_left--;
     if (base >= nslots) break;
     const bool has_q = base + team < nslots;
     const int32_t slot = has_q ? (slots ? slots[base + team] : base + team) : 0;
@@ -1606,21 +1631,25 @@ __global__ void __launch_bounds__(kTeamBlock) TKNN_WALK_ATTR team_walk_kernel(Te
               a.out_fb[o] = ev;
             }
           }
-          bool tie = false;
+          bool tie = false, edge = false;
           const float qmax = fmaxf(fmaxf(fabsf(q.x), fabsf(q.y)), fabsf(q.z));
 #pragma unroll
           for (int reg = 0; reg < NREG; reg++) {
             uint32_t before = t_team_shr1(bd[reg]);
             if (reg > 0) before |= t_dpp<0x121>(bd[reg - 1]) & (tl == 0 ? 0xffffffffu : 0u);
             bool t = ((reg > 0) | (tl >= 1)) & (16 * reg + tl <= a.k) & (bd[reg] == before);
-            if (reg == NREG - 1 && full) t |= (tl == 15) & (left_out == bd[reg]);
-            tie |= t && tie_may_straddle(__uint_as_float(bd[reg]), q_r0, r, qmax, a.tie_span);
+            const bool out_t = reg == NREG - 1 && full && tl == 15 && left_out == bd[reg];
+            t |= out_t;
+            t = t && tie_may_straddle(__uint_as_float(bd[reg]), q_r0, r, qmax, a.tie_span);
+            tie |= t;
+            edge |= t && (16 * reg + tl == a.k || out_t);  // (a tie with a candidate that is not written: knn_flag_tie)
           }
           const bool tied = ((uint32_t)(__ballot(tie) >> (team * 16)) & 0xffffu) != 0u;
+          const bool tied_edge = ((uint32_t)(__ballot(edge) >> (team * 16)) & 0xffffu) != 0u;
           if (tl == 0) {
             if (a.out_isect) a.out_isect[row] = isect;
             if (a.out_level) a.out_level[row] = level;
-            if (tied) knn_flag_tie(a.tie, a.tie_list, a.counters, slot, level);
+            if (tied) knn_flag_tie(a.tie, a.tie_list, a.counters, slot, level, tied_edge);
             a.done[slot] = 1;
             isect_sum += (unsigned long long)isect;
           }
@@ -1719,18 +1748,26 @@ __global__ void __launch_bounds__(kTeamBlock) tie_fix_kernel(TeamArgs a, const i
     levels[t][l].count = a.wide[t].count[l];
   }
   t_wave_sync();
-  unsigned int failed = 0;
+  unsigned int failed = 0, stood = 0;
+  int turn_next = 0, turn_left = 0;  // (as in team_walk_kernel)
   for (;;) {
-    int base = 0;
-    if (lane == 0) base = (int)atomicAdd(&a.counters[kTieCounter + 1], 4ull);
-    base = __builtin_amdgcn_readfirstlane(base);
+    if (turn_left == 0) {
+      int got = 0;
+      if (lane == 0) got = (int)atomicAdd(&a.counters[kTieCounter + 1], 4ull * (unsigned long long)max(a.grab, 1));
+      turn_next = __builtin_amdgcn_readfirstlane(got);
+      turn_left = max(a.grab, 1);
+    }
+    const int base = turn_next;
+    turn_next += 4;
+    turn_left--;
     if (base >= nslots) break;
     bool active = base + team < nslots;
     const int32_t slot = active ? slots[base + team] : 0;
     const LbvhPoint q = a.bvh.points[slot];
     const int32_t row = a.bvh.prim_id[slot];
-    active = active && a.tie[slot] != 0;  // a listed slot that is not flagged (any more) keeps its row
-    const int level = active ? (int)a.tie[slot] - 1 : 0;
+    const uint32_t tie_word = active ? (uint32_t)a.tie[slot] : 0u;
+    active = active && tie_word != 0u;  // a listed slot that is not flagged (any more) keeps its row
+    const int level = active ? (int)(tie_word & 0x7fu) - 1 : 0;
     const float q_r0 = a.start_radii ? a.start_radii[row] : a.start_radius;
     float r = q_r0;
     for (int i = 0; i < level; i++) r = r * 2.0f;
@@ -1767,6 +1804,57 @@ __global__ void __launch_bounds__(kTeamBlock) tie_fix_kernel(TeamArgs a, const i
         tau2 = knn_gate_from_worst(a.out_dist[last]);
       else if (a.out_fb)
         tau2 = knn_gate_from_worst(a.out_fb[last].dist);
+    }
+    // Every tie of the row between two WRITTEN entries (no `edge`): the row is in (distance, index) order already, which is the
+    // full key's order unless two tied neighbours became candidates at different levels.  Look that up from the row -- two
+    // points per tied pair -- before walking for it: the duplicates of a data set (taxi pick-ups at one street corner) tie in
+    // every row that holds both, always at one level, and are most of what is flagged on such sets (10 M taxi-like points with
+    // 5 % duplicates, k = 10: 0.78 M rows flagged, 2.5 of the solve's 13.1 ms in this pass before this check).
+    if (!HALO && a.row_slot && __ballot(active && !(tie_word & 0x80u)) != 0ull) {
+      bool differs = false;
+      const bool look = active && !(tie_word & 0x80u);
+      uint32_t rd[NREG], ri[NREG];
+#pragma unroll
+      for (int reg = 0; reg < NREG; reg++) {
+        const int j = tl + 16 * reg;
+        rd[reg] = 0xffffffffu;  // (no entry: never equal to a distance)
+        ri[reg] = 0u;
+        if (look && j < a.k) {
+          const int64_t o = (int64_t)row * a.k + j;
+          if (a.out_dist && a.out_idx) {
+            rd[reg] = __float_as_uint(a.out_dist[o]);
+            ri[reg] = (uint32_t)a.out_idx[o];
+          } else if (a.out_fb) {
+            rd[reg] = __float_as_uint(a.out_fb[o].dist);
+            ri[reg] = (uint32_t)a.out_fb[o].ind;
+          } else {
+            differs = true;  // (indices without distances: nothing to compare)
+          }
+        }
+      }
+#pragma unroll
+      for (int reg = 0; reg < NREG; reg++) {
+        uint32_t pd = t_team_shr1(rd[reg]), pi = t_team_shr1(ri[reg]);
+        if (reg > 0) {
+          const uint32_t lane0 = tl == 0 ? 0xffffffffu : 0u;
+          pd = (pd & ~lane0) | (t_dpp<0x121>(rd[reg - 1]) & lane0);
+          pi = (pi & ~lane0) | (t_dpp<0x121>(ri[reg - 1]) & lane0);
+        }
+        const int j = tl + 16 * reg;
+        if (look && j >= 1 && j < a.k && rd[reg] == pd) {
+          if (ri[reg] >= (uint32_t)a.bvh.n || pi >= (uint32_t)a.bvh.n) {
+            differs = true;
+          } else {
+            const LbvhPoint pa = a.bvh.points[a.row_slot[ri[reg]]], pb = a.bvh.points[a.row_slot[pi]];
+            differs |= first_level(pa) != first_level(pb);
+          }
+        }
+      }
+      const bool team_differs = ((uint32_t)(__ballot(differs) >> (team * 16)) & 0xffffu) != 0u;
+      if (look && !team_differs) {  // the row stands
+        active = false;
+        stood += tl == 0 ? 1u : 0u;
+      }
     }
     bool overflow = false;
     for (int tree = 0; tree < (HALO ? 2 : 1); tree++) {
@@ -1896,6 +1984,8 @@ __global__ void __launch_bounds__(kTeamBlock) tie_fix_kernel(TeamArgs a, const i
   }
   const unsigned long long fsum = t_wave_sum((unsigned long long)failed);
   if (lane == 0 && fsum) atomicAdd(&a.counters[kTieCounter + 2], fsum);
+  const unsigned long long ssum = t_wave_sum((unsigned long long)stood);
+  if (lane == 0 && ssum) atomicAdd(&a.counters[kTieCounter + 3], ssum);
 }
 
 
@@ -1973,10 +2063,17 @@ __global__ void __launch_bounds__(kTeamBlock) TKNN_BIGK_ATTR bigk_walk_kernel(Te
   unsigned long long isect_sum = 0, levels_sum = 0, node_tests = 0, point_tests = 0;
   unsigned int unfinished = 0, failed = 0;
   int max_level = 0;
+  int turn_next = 0, turn_left = 0;  // (as in team_walk_kernel)
   for (;;) {
-    int base = 0;
-    if (lane == 0) base = (int)atomicAdd(&a.counters[0], 4ull);
-    base = __builtin_amdgcn_readfirstlane(base);
+    if (turn_left == 0) {
+      int got = 0;
+      if (lane == 0) got = (int)atomicAdd(&a.counters[0], 4ull * (unsigned long long)max(a.grab, 1));
+      turn_next = __builtin_amdgcn_readfirstlane(got);
+      turn_left = max(a.grab, 1);
+    }
+    const int base = turn_next;
+    turn_next += 4;
+    turn_left--;
     if (base >= n) break;
     const int32_t slot = min(base + team, n - 1);
     bool has_q = base + team < n;
@@ -2295,6 +2392,7 @@ void Engine::solve_bigk(const SolveArgs &sa, tknnSolveInfo *info, hipStream_t s)
   {
     BigKey *lists = (BigKey *)wave_ws_;
     int ch = chunks;
+    a.grab = 1;
     void *kargs[] = {(void *)&a, (void *)&lists, (void *)&ch};
     OWLMI_HIP(hipLaunchKernel(entry, dim3(blocks), dim3(kTeamBlock), kargs, 0, s));
   }
@@ -2329,7 +2427,8 @@ void Engine::solve_bigk(const SolveArgs &sa, tknnSolveInfo *info, hipStream_t s)
 }
 
 
-void Engine::launch_tie_fix(const SolveArgs &sa, const int32_t *slots, int32_t nslots, int blocks, hipStream_t s, const int32_t *d_slot_count) {
+void Engine::launch_tie_fix(const SolveArgs &sa, const int32_t *slots, int32_t nslots, int blocks, hipStream_t s, const int32_t *d_slot_count,
+                            int64_t expected_rows) {
   TeamArgs a;
   std::memset(&a, 0, sizeof a);
   a.bvh = bvh_.view();
@@ -2345,6 +2444,10 @@ void Engine::launch_tie_fix(const SolveArgs &sa, const int32_t *slots, int32_t n
   a.tie = tie_;
   a.tie_list = tie_list_;
   a.slot_count = d_slot_count;
+  // (10 M taxi-like points, k = 10 / 24, 0.78 / 2.3 M rows, 24 workgroups per CU: turns of 4 / 8 / 12 / 24 / 32 slots 2.55 / 1.42 / 1.08 /
+  // 0.89 / 0.94 ms and 7.2 / 3.8 / 2.6 / 1.81 / 1.85 ms; 64 and more slots a turn: the waves' own chains of loads show, 2.8 ms and up)
+  a.grab = grab_for(expected_rows, blocks, 6, 6);
+  a.row_slot = getenv("TKNN_TIE_LOOK") && !strcmp(getenv("TKNN_TIE_LOOK"), "0") ? nullptr : bvh_.row_slot_device();  // (A/B switch)
   a.counters = counters_;
   using FixEntry = void (*)(TeamArgs, const int32_t *, int32_t);
   static const FixEntry entries[2][4] = {{tie_fix_kernel<false, 1>, tie_fix_kernel<false, 2>, tie_fix_kernel<false, 3>, tie_fix_kernel<false, 4>},
@@ -2369,16 +2472,16 @@ void Engine::fix_ties(const SolveArgs &sa, tknnSolveInfo *info, hipStream_t s) {
   const int64_t n = bvh_.size();
   hipDeviceProp_t prop;
   OWLMI_HIP(hipGetDeviceProperties(&prop, device_));
-  auto launch = [&](int blocks, const int32_t *slots, int32_t nslots, const int32_t *d_len = nullptr) {
-    launch_tie_fix(sa, slots, nslots, blocks, s, d_len);
+  auto launch = [&](int blocks, const int32_t *slots, int32_t nslots, const int32_t *d_len = nullptr, int64_t expected = 0) {
+    launch_tie_fix(sa, slots, nslots, blocks, s, d_len, expected);
   };
-  OWLMI_HIP(hipMemsetAsync(counters_ + kTieCounter + 1, 0, 2 * sizeof(unsigned long long), s));  // work cursor, rows left
+  OWLMI_HIP(hipMemsetAsync(counters_ + kTieCounter + 1, 0, 3 * sizeof(unsigned long long), s));  // work cursor, rows left
   // First go: the kernels' own list, count read on the device -- no host round trip before the launch;
   // the usual handful of rows (or none) costs one small launch behind the solve.
   OWLMI_HIP(hipEventRecord(ev_a_, s));
   launch(std::min(prop.multiProcessorCount * 4, kTieListCap / 4), tie_list_, -1);  // a team per listed row
   OWLMI_HIP(hipEventRecord(ev_b_, s));
-  OWLMI_HIP(hipMemcpyAsync(h_counters_, counters_ + kTieCounter, 3 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+  OWLMI_HIP(hipMemcpyAsync(h_counters_, counters_ + kTieCounter, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
   OWLMI_HIP(hipStreamSynchronize(s));
   float ms = 0;
   OWLMI_HIP(hipEventElapsedTime(&ms, ev_a_, ev_b_));
@@ -2404,18 +2507,21 @@ void Engine::fix_ties(const SolveArgs &sa, tknnSolveInfo *info, hipStream_t s) {
       wave_ws_bytes_ = tmp_bytes;
     }
     OWLMI_HIP(hipcub::DeviceSelect::Flagged(wave_ws_, tmp_bytes, iota, flags, slot_list_, d_count, (int)n, s));
-    OWLMI_HIP(hipMemsetAsync(counters_ + kTieCounter + 1, 0, 2 * sizeof(unsigned long long), s));
+    OWLMI_HIP(hipMemsetAsync(counters_ + kTieCounter + 1, 0, 3 * sizeof(unsigned long long), s));
     OWLMI_HIP(hipEventRecord(ev_a_, s));
     // the list's length is read on the device (d_count): `flagged` counts flag calls, an upper bound
-    launch((int)std::min<int64_t>((std::min<int64_t>(flagged, n) + 3) / 4, (int64_t)prop.multiProcessorCount * 16), slot_list_, -2, d_count);
+    launch((int)std::min<int64_t>((std::min<int64_t>(flagged, n) + 3) / 4, (int64_t)prop.multiProcessorCount * 24), slot_list_, -2, d_count,
+           std::min<int64_t>(flagged, n));
     OWLMI_HIP(hipEventRecord(ev_b_, s));
-    OWLMI_HIP(hipMemcpyAsync(h_counters_, counters_ + kTieCounter, 3 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+    OWLMI_HIP(hipMemcpyAsync(h_counters_, counters_ + kTieCounter, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
     OWLMI_HIP(hipStreamSynchronize(s));
     float again = 0;
     OWLMI_HIP(hipEventElapsedTime(&again, ev_a_, ev_b_));
     ms += again;
   }
-  if (flagged && getenv("TKNN_VERBOSE")) fprintf(stderr, "[ties] %lld rows redone in the reference's tie order: %.3f ms, %llu left\n", (long long)flagged, ms, h_counters_[2]);
+  if (flagged && getenv("TKNN_VERBOSE"))
+    fprintf(stderr, "[ties] %lld rows redone in the reference's tie order: %.3f ms, %llu left (%llu stood after a look at the written row)\n", (long long)flagged, ms,
+            h_counters_[2], h_counters_[3]);
   if (info) {
     info->tie_rows = flagged;
     info->tie_rows_left = (int64_t)h_counters_[2];
@@ -2508,6 +2614,7 @@ bool Engine::solve_team(const SolveArgs &sa, tknnSolveInfo *info, hipStream_t s)
     OWLMI_HIP(hipMemsetAsync(next_level_, 0, (size_t)n * sizeof(int32_t), s));
     if (sa.d_levels) OWLMI_HIP(hipMemsetAsync(sa.d_levels, 0xff, (size_t)n * sizeof(int32_t), s));
     const int walk_blocks = (int)std::min<int64_t>((n + 3) / 4, (int64_t)prop.multiProcessorCount * kWalkBlocksPerCu);
+    a.grab = 1;  // (queries differ too much for longer turns: measured, see TeamArgs::grab)
     OWLMI_HIP(hipEventRecord(ev_a_, s));
     if (with_halo)
       hipLaunchKernelGGL((team_walk_kernel<true, 4>), dim3(walk_blocks), dim3(kTeamBlock), 0, s, a, (const int32_t *)nullptr, (int32_t)n);
@@ -2696,6 +2803,7 @@ bool Engine::solve_team(const SolveArgs &sa, tknnSolveInfo *info, hipStream_t s)
                                               {team_walk_kernel<true, 1>, team_walk_kernel<true, 2>, team_walk_kernel<true, 3>, team_walk_kernel<true, 4>}};
         const int32_t *slots = slot_list_;
         int32_t nslots = (int32_t)handed;
+        a.grab = 1;
         void *kargs[] = {(void *)&a, (void *)&slots, (void *)&nslots};
         OWLMI_HIP(hipLaunchKernel((const void *)walks[with_halo ? 1 : 0][nreg_at], dim3(walk_blocks), dim3(kTeamBlock), kargs, 0, s));
       }

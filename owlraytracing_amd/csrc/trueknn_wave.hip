@@ -44,7 +44,7 @@ struct WaveArgs {
   LbvhView halo;      // second point set searched by every query (n == 0: none)
   int32_t *out_level; // n, caller order (may be null)
   const uint8_t *skip_done;  // per sorted slot, may be null: queries another kernel has finished already
-  uint8_t *tie;              // per sorted slot: 1 + level for rows finished with exact-distance ties (knn_flag_tie)
+  uint8_t *tie;              // per sorted slot: (1 + level) | 0x80 for rows finished with exact-distance ties (knn_flag_tie)
   int32_t *tie_list;
   int allow_unfinished;
   float start_radius;

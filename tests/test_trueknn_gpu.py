@@ -269,6 +269,39 @@ def test_tie_heavy_sets_equal_the_replay(kernel, tail, k, monkeypatch):
         eng.close()
 
 
+@pytest.mark.parametrize("look", ["1", "0"])
+@pytest.mark.parametrize("k", [5, 16, 24, 48])
+def test_ties_between_duplicates_keep_their_rows(k, look, monkeypatch):
+    """Duplicated points tie in every row that holds both copies, always as candidates of one level: the tie pass looks at
+    the written row first and walks only for rows whose tied neighbours differ in level (or tie with a candidate left out).
+    Sets: uniform points with a quarter of them copies; the taxi-like set (5 % copies, heavy tails); a lattice with holes --
+    ties across levels, the walk's case -- with copies on top.  TKNN_TIE_LOOK=0 is the pass without the look: same rows."""
+    monkeypatch.setenv("TKNN_TIE_LOOK", look)
+    rng = np.random.default_rng(100 + k)
+    uni = datasets.uniform3d(24_000, seed=k)
+    uni[rng.choice(len(uni), 6000, replace=False)] = uni[rng.integers(0, len(uni), 6000)]
+    lat = _lattice(22, 3, k)
+    lat = np.ascontiguousarray(np.concatenate([lat, lat[rng.integers(0, len(lat), len(lat) // 5)]])[rng.permutation(len(lat) + len(lat) // 5)])
+    sets = [(uni, datasets.start_radius(len(uni), k)), (datasets.pad_to_3d(datasets.taxi_like2d(30_000, components=12, seed=k)), 0.002),
+            (lat, 0.02)]
+    flagged = 0
+    for xyz, r0 in sets:
+        ref = oracle.trueknn(xyz, k, r0)
+        eng = _engine()
+        eng.build(xyz)
+        r = eng.solve(k, r0, kernel=_lib.KERNEL_TEAM)
+        assert np.array_equal(r["intersections"].cpu().numpy(), ref["intersections"])
+        assert_rows_equal(r["idx"].cpu().numpy(), r["dist"].cpu().numpy(), ref["idx"], ref["dist"])
+        assert r["info"]["tie_rows_left"] == 0
+        flagged += r["info"]["tie_rows"]
+        fb = _fb_view(eng.solve(k, r0, kernel=_lib.KERNEL_TEAM, fb_only=True)["fb"], len(xyz), k)  # (the look reads the records)
+        want = ref["fb"].reshape(len(xyz), k)
+        for field in ("ind", "dist"):
+            assert np.array_equal(fb[field], want[field]), field
+        eng.close()
+    assert flagged > 100
+
+
 def test_wave_kernel_redo_path_with_more_tie_rows_than_the_list_holds(monkeypatch):
     """The wave kernel re-solves its queries when its LDS stack overflows; TKNN_WAVE_FORCE_REDO takes that path without a
     pathological tree.  On a lattice nearly every row is flagged for the tie pass: more than the 4096 the device-side
