@@ -53,10 +53,18 @@ constexpr int kTieListCap = 4096;
 // edge: one of the tied candidates may be the best one LEFT OUT of the row (or the kernel cannot tell): only a walk finds it.
 // Without it every tie lies between two written entries, and tie_fix_kernel first looks whether the pairs' candidates became
 // candidates at the same level (coincident points -- duplicates of a data set -- always do): then the row stands as it is.
+// edge = 2: bit 7 of tie[slot] says so already (the packet kernel's SELECT pass sets it where it sees such a tie, long before
+// the row is finished: team_pass) -- a byte with bit 7 alone is not a flag.
+__device__ __forceinline__ void knn_note_tie_edge(uint8_t *tie, int32_t slot) {
+  atomicOr(reinterpret_cast<unsigned int *>(tie + (slot & ~3)), 0x80u << (8 * (slot & 3)));
+}
 __device__ __forceinline__ void knn_flag_tie(uint8_t *tie, int32_t *tie_list, unsigned long long *counters, int32_t slot, int level,
-                                             bool edge = true) {
+                                             int edge = 1) {
   if (level >= 127) return;  // (tknnSolve caps max_rounds at 127)
-  tie[slot] = (uint8_t)((1 + level) | (edge ? 0x80 : 0));
+  if (edge == 2)  // (an atomic on the byte's word: the note came from another lane, through memory)
+    atomicOr(reinterpret_cast<unsigned int *>(tie + (slot & ~3)), (unsigned int)(1 + level) << (8 * (slot & 3)));
+  else
+    tie[slot] = (uint8_t)((1 + level) | (edge ? 0x80 : 0));
   const unsigned long long pos = atomicAdd(&counters[kTieCounter], 1ull);
   if (pos < (unsigned long long)kTieListCap) tie_list[pos] = slot;
 }

@@ -352,7 +352,7 @@ void Engine::build(const float *d_xyz, const int32_t *d_ids, int64_t n, tknnBuil
       OWLMI_HIP(hipMalloc((void **)&done_, (size_t)n));
       OWLMI_HIP(hipMalloc((void **)&isect_sorted_, (size_t)n * sizeof(int64_t)));
       OWLMI_HIP(hipMalloc((void **)&next_level_, (size_t)n * sizeof(int32_t)));
-      OWLMI_HIP(hipMalloc((void **)&tie_, (size_t)n));
+      OWLMI_HIP(hipMalloc((void **)&tie_, ((size_t)n + 3) & ~(size_t)3));  // (whole words: knn_flag_tie's atomics work on the byte's word)
       OWLMI_HIP(hipMalloc((void **)&boundary_, (size_t)n));
     } catch (...) {
       bvh_.clear();  // unbuilt: tknnSolve then answers TKNN_E_STATE instead of launching on null arrays

@@ -787,11 +787,11 @@ __device__ __forceinline__ void team_pass(const TeamArgs &a, const TeamLds &L, i
     const uint32_t self = cnt ? 1u : 0u;  // a query lies in its own box, and ids are unique
     const uint32_t others = cnt - self;
     if (TWO) cnt_i0 = t_team_sum(cnt_i0);
-    uint32_t tied = 0u;  // bit 0: the row has ties that may span two rounds, bit 1: ... one of them with the best candidate left out
+    uint32_t tied = 0u;
     if (SELECT) {
       // entry j against entry j - 1, for j = 1..k (KList::has_ties is the per-lane form of this)
       bool tie[NREG];
-      bool any = false, edge = false;
+      bool any = false;
 #pragma unroll
       for (int j = 0; j < NREG; j++) {
         uint32_t before = t_team_shr1(bd[j]);
@@ -803,6 +803,7 @@ __device__ __forceinline__ void team_pass(const TeamArgs &a, const TeamLds &L, i
       if (__ballot(any) != 0ull) {  // rare: does any of them span two rounds?
         const float qmax = fmaxf(fmaxf(fabsf(t_qx), fabsf(t_qy)), fabsf(t_qz));
         any = false;
+        bool edge = false;
         const float q_r0 = a.start_radii ? a.start_radii[a.bvh.prim_id[first_slot + qi]] : a.start_radius;
 #pragma unroll
         for (int j = 0; j < NREG; j++) {
@@ -811,15 +812,18 @@ __device__ __forceinline__ void team_pass(const TeamArgs &a, const TeamLds &L, i
           // ... with a candidate that is not written: entry k of a list with room to spare, the best one left out of a full list
           edge |= t && (16 * j + tl == a.k || (full && j == NREG - 1 && tl == 15 && left_out == bd[j]));
         }
+        // (said to knn_flag_tie through the flag byte itself, here in the rare branch: a second bit through the passes' count
+        // words and the level loop moved the packet kernel's register allocation -- 0.6 % of the benchmark)
+        if (on && edge) knn_note_tie_edge(a.tie, first_slot + qi);
       }
-      tied = (((uint32_t)(__ballot(any) >> (team * 16)) & 0xffffu) ? 1u : 0u) | (((uint32_t)(__ballot(edge) >> (team * 16)) & 0xffffu) ? 2u : 0u);
+      tied = ((uint32_t)(__ballot(any) >> (team * 16)) & 0xffffu) ? 1u : 0u;
     }
     if (on && tl == 0) {
       // counts innermost level first; a one-level pass fills slot 0
       uint32_t *out = L.qcnt + qi * 2;
       if (!TWO) {
         out[0] = cnt;
-        out[1] = (self << 31) | ((tied & 1u) << 30) | ((tied >> 1) << 29);
+        out[1] = (self << 31) | (tied << 30);
       } else {
         out[0] = cnt_i0;
         out[1] = cnt | (self << 31);
@@ -1349,8 +1353,7 @@ __global__ void __launch_bounds__(kTeamBlock) __attribute__((amdgpu_waves_per_eu
         if (a.out_fb) a.out_fb[(int64_t)row * a.k].intersections = isect;
         const int fin_level = level + (fin_at > 0 ? fin_at : 0);
         if (a.out_level) a.out_level[row] = fin_level;
-        if ((qcnt[lane * 2 + 1] >> 30) & 1u)  // SELECT saw exact-distance ties
-          knn_flag_tie(a.tie, a.tie_list, a.counters, slot, fin_level, ((qcnt[lane * 2 + 1] >> 29) & 1u) != 0u);
+        if ((qcnt[lane * 2 + 1] >> 30) & 1u) knn_flag_tie(a.tie, a.tie_list, a.counters, slot, fin_level, 2);  // SELECT saw exact-distance ties
       }
       active = active && !finished;
       level += m;
@@ -1649,7 +1652,7 @@ __global__ void __launch_bounds__(kTeamBlock) TKNN_WALK_ATTR team_walk_kernel(Te
           if (tl == 0) {
             if (a.out_isect) a.out_isect[row] = isect;
             if (a.out_level) a.out_level[row] = level;
-            if (tied) knn_flag_tie(a.tie, a.tie_list, a.counters, slot, level, tied_edge);
+            if (tied) knn_flag_tie(a.tie, a.tie_list, a.counters, slot, level, tied_edge ? 1 : 0);
             a.done[slot] = 1;
             isect_sum += (unsigned long long)isect;
           }
@@ -1723,7 +1726,7 @@ __global__ void __launch_bounds__(256) team_prep_kernel(uint8_t *done, uint8_t *
 constexpr int kFixStack = 384;  // as the walk: 6 KB of LDS per wave leaves room for 16 waves per CU; the ball pruning keeps stacks far below
 
 struct HasTie {
-  __host__ __device__ bool operator()(uint8_t t) const { return t != 0; }
+  __host__ __device__ bool operator()(uint8_t t) const { return (t & 0x7f) != 0; }  // (bit 7 alone: team_pass's note, no flag)
 };
 
 template <bool HALO, int NREG>
@@ -1766,7 +1769,7 @@ __global__ void __launch_bounds__(kTeamBlock) tie_fix_kernel(TeamArgs a, const i
     const LbvhPoint q = a.bvh.points[slot];
     const int32_t row = a.bvh.prim_id[slot];
     const uint32_t tie_word = active ? (uint32_t)a.tie[slot] : 0u;
-    active = active && tie_word != 0u;  // a listed slot that is not flagged (any more) keeps its row
+    active = active && (tie_word & 0x7fu) != 0u;  // a listed slot that is not flagged (any more) keeps its row
     const int level = active ? (int)(tie_word & 0x7fu) - 1 : 0;
     const float q_r0 = a.start_radii ? a.start_radii[row] : a.start_radius;
     float r = q_r0;
