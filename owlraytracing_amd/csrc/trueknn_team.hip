@@ -130,6 +130,10 @@ inline int nreg_for(int k) { return k <= 16 ? 1 : (k <= 32 ? 2 : (k <= 48 && TKN
 #define TKNN_BIGK_ATTR
 #endif
 constexpr int kWalkBlocksPerCu = 4 * (TKNN_WALK_WAVES > 4 ? TKNN_WALK_WAVES : 4);  // one-wave workgroups of the walks' launches
+// the per-XCD packet counters: 256 bytes apart, behind the kCounters words (the words RT-DBSCAN stripes its statistics over: not in
+// use during a solve).  Side by side in one cache line (round 3: counters[16 + x]) their atomics -- one per packet, 156 000 per launch
+// of the benchmark -- queued at one place (see TeamArgs::grab for what a turn at one address costs)
+constexpr int kXcdCounter = kCounters, kXcdCounterStride = 32;
 constexpr int kTeamStack = 192;     // wide-pyramid stack entries per wave
 constexpr int kQrecStride = 6;      // floats per LDS query record (layout below)
 constexpr int kScanBudget = 16384;  // leaf blocks one packet-level may test against its queries before it is handed over
@@ -223,7 +227,7 @@ struct TeamArgs {
   // (turns of up to 64 slots: the hand-over walk 4.0 -> 4.5 ms on that set, the k = 65 walk 173 -> 189 ms on 10 M uniform points).
   int grab;
   const int32_t *row_slot;    // tie_fix_kernel: the sorted slot of row i (Lbvh::row_slot_device), or null: no look at the written row first
-  // [0] (unused here) [16..23] per-XCD packet counters [1] max levels [2] node tests [3] point tests [4] sum isect
+  // [0] (unused here) [kXcdCounter + 32 x] per-XCD packet counters [1] max levels [2] node tests [3] point tests [4] sum isect
   // [5] error flags (1 max_rounds) [6] sum levels [7] unfinished [8] handed over [9] min hand-over level
   unsigned long long *counters;
 };
@@ -914,7 +918,7 @@ __global__ void __launch_bounds__(kTeamBlock) __attribute__((amdgpu_waves_per_eu
       const int x = (xcc + t) & 7;
       if (seg_empty & (1u << x)) continue;
       int v = 0;
-      if (lane == 0) v = (int)atomicAdd(&a.counters[16 + x], 1ull);
+      if (lane == 0) v = (int)atomicAdd(&a.counters[kXcdCounter + kXcdCounterStride * x], 1ull);
       v = __builtin_amdgcn_readfirstlane(v);
       const int cand = ((v / chunk) * 8 + x) * chunk + (v % chunk);  // v-th packet of XCD x
       if (cand < a.ngroups)
@@ -1695,7 +1699,7 @@ __global__ void __launch_bounds__(kTeamBlock) TKNN_WALK_ATTR team_walk_kernel(Te
 // over), tie[] = 0, counters = 0 except [9] = ~0 (min hand-over level), levels[] = -1 if asked for.
 __global__ void __launch_bounds__(256) team_prep_kernel(uint8_t *done, uint8_t *tie, int64_t n, unsigned long long *counters, int32_t *levels) {
   const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, nth = (int64_t)gridDim.x * blockDim.x;
-  if (tid < kCounters) counters[tid] = tid == 9 ? ~0ull : 0ull;
+  if (tid < kCounters + 8 * kXcdCounterStride) counters[tid] = tid == 9 ? ~0ull : 0ull;  // (+ the per-XCD packet counters behind them)
   // hipMalloc'd arrays are 256-byte aligned: whole 16-byte words, then the last few bytes
   const int64_t words = n / 16;
   uint4 *d16 = reinterpret_cast<uint4 *>(done), *t16 = reinterpret_cast<uint4 *>(tie);
@@ -2601,6 +2605,7 @@ bool Engine::solve_team(const SolveArgs &sa, tknnSolveInfo *info, hipStream_t s)
   hipDeviceProp_t prop;
   OWLMI_HIP(hipGetDeviceProperties(&prop, device_));
   int per_cu = 2;
+  static_assert(kDbStripes * 8 >= 8 * kXcdCounterStride, "the packet counters borrow the words of RT-DBSCAN's striped statistics");
   const int nreg = nreg_for(sa.k);  // list registers per lane
   const size_t lds = (size_t)kTeamBlock / 64 * (size_t)(nreg == 1 ? TeamLayout<1>::kTeamLds : (nreg == 2 ? TeamLayout<2>::kTeamLds
                                                          : (nreg == 3 ? TeamLayout<3>::kTeamLds : TeamLayout<4>::kTeamLds)));
