@@ -82,6 +82,9 @@ struct DbArgs {
 // atomic per workgroup (every thread of the workgroup must call it).  `stats` = a.stats + 2 * (which kernel): the counters
 // are kept in 32 stripes of 8 words, a workgroup adds to the stripe of its index, the host sums them.
 constexpr int kDbStripes = 32;
+// the group-union kernel's per-XCD packet cursors: a cache line each (side by side their atomics -- one per packet, its answer
+// awaited, and up to eight per wave that finds the lists used up -- queue at one place: trueknn_team.hip, kXcdCounter)
+constexpr int kDbCursorStride = 32;
 __device__ __forceinline__ void db_add_stats(unsigned long long *stats, unsigned long long *blk, uint32_t nodes, uint32_t points) {
   stats += (blockIdx.x & (kDbStripes - 1)) * 8;
 #pragma unroll
@@ -939,7 +942,7 @@ __global__ void __launch_bounds__(kDbUnionBlock) __attribute__((amdgpu_waves_per
       const int from = (xcc + t) & 7;
       if (seg_empty & (1u << from)) continue;
       unsigned long long v = 0;
-      if (lane == 0) v = atomicAdd(next_packet + from, 1ull);
+      if (lane == 0) v = atomicAdd(next_packet + from * kDbCursorStride, 1ull);
       v = __shfl(v, 0);
       const long long p = (((long long)v / chunk) * 8 + from) * chunk + (long long)v % chunk;
       if (p < packets)
@@ -1589,7 +1592,7 @@ int64_t Engine::dbscan_noise(float eps, int min_pts, uint8_t *d_noise, hipStream
   a.stats = counters_ + kCounters;  // striped (db_add_stats)
   void *scan_tmp = ws + need;
   const unsigned blocks = (unsigned)((n + kDbBlock - 1) / kDbBlock), blocks1 = (unsigned)((n + 1 + kDbBlock - 1) / kDbBlock);
-  OWLMI_HIP(hipMemsetAsync(counters_, 0, (kCounters + kDbStripes * 8) * sizeof(unsigned long long), s));
+  OWLMI_HIP(hipMemsetAsync(counters_, 0, kCounterWords * sizeof(unsigned long long), s));
   hipLaunchKernelGGL(db_core_kernel, dim3(blocks), dim3(kDbBlock), 0, s, a, (int32_t *)nullptr);
   {
     int32_t *pos = a.rank;
@@ -1673,7 +1676,7 @@ void Engine::dbscan(float eps, int min_pts, int32_t *d_labels, uint8_t *d_core, 
     OWLMI_HIP(hipStreamWaitEvent(s, ev_side_b_, 0));
     db_side_pending_ = false;
   }
-  OWLMI_HIP(hipMemsetAsync(counters_, 0, (kCounters + kDbStripes * 8) * sizeof(unsigned long long), s));  // ... [19]: length of the label pass's list
+  OWLMI_HIP(hipMemsetAsync(counters_, 0, kCounterWords * sizeof(unsigned long long), s));  // ... [19]: length of the label pass's list
   const unsigned walk_grid = blocks < 2048u ? blocks : 2048u;  // grid-stride over lists whose lengths only the device knows
   hipEvent_t e0 = ev_a_, e1 = ev_b_;
   OWLMI_HIP(hipEventRecord(e0, s));
@@ -1729,9 +1732,10 @@ void Engine::dbscan(float eps, int min_pts, int32_t *d_labels, uint8_t *d_core, 
     hipLaunchKernelGGL(db_union_kernel, dim3(blocks), dim3(kDbBlock), 0, s, a);
   } else {
     // per-slot group references where the ranks go afterwards, the list itself (slot order = Morton order: neighbours in
-    // the list are neighbours in space) where the root flags go; its length in counters_[8], the XCDs' cursors in [9..16]
+    // the list are neighbours in space) where the root flags go; its length in counters_[8], the XCDs' cursors behind the statistics' stripes
     int32_t *group_at = a.rank, *groups = is_root;
     unsigned long long *n_groups = counters_ + 8;
+    unsigned long long *cursors = counters_ + kCounters + kDbStripes * 8;  // (behind the statistics' stripes, kDbCursorStride apart)
     // (... and the count of stack overflows in [17]; all zero since the call's first memset)
     a.chunk = getenv("TKNN_DB_CHUNK") ? std::max(1, atoi(getenv("TKNN_DB_CHUNK"))) : 64;
     a.short_way = getenv("TKNN_DB_SHORT") ? atoi(getenv("TKNN_DB_SHORT")) : 1;
@@ -1776,8 +1780,8 @@ void Engine::dbscan(float eps, int min_pts, int32_t *d_labels, uint8_t *d_core, 
     OWLMI_HIP(hipEventRecord(ev_d_, s));
     if (split < 1.f) {
       union_launches = 2;
-      hipLaunchKernelGGL(db_group_union_kernel, dim3(grid), dim3(kDbUnionBlock), 0, s, a, groups, n_groups, n_groups + 1, n_groups + 9);
-      OWLMI_HIP(hipMemsetAsync(n_groups + 1, 0, 8 * sizeof(unsigned long long), s));
+      hipLaunchKernelGGL(db_group_union_kernel, dim3(grid), dim3(kDbUnionBlock), 0, s, a, groups, n_groups, cursors, n_groups + 9);
+      OWLMI_HIP(hipMemsetAsync(cursors, 0, 8 * kDbCursorStride * sizeof(unsigned long long), s));
       a.near_lo2 = a.near_hi2;
       OWLMI_HIP(hipEventRecord(ev_g_, s));
       between_passes = true;
@@ -1792,7 +1796,7 @@ void Engine::dbscan(float eps, int min_pts, int32_t *d_labels, uint8_t *d_core, 
     }
     a.near_hi2 = a.eps_out2;
     a.reach = db_reach_of(a.near_hi2);
-    hipLaunchKernelGGL(db_group_union_kernel, dim3(grid), dim3(kDbUnionBlock), 0, s, a, groups, n_groups, n_groups + 1, n_groups + 9);
+    hipLaunchKernelGGL(db_group_union_kernel, dim3(grid), dim3(kDbUnionBlock), 0, s, a, groups, n_groups, cursors, n_groups + 9);
   }
   OWLMI_HIP(hipEventRecord(ev_e_, s));
   if (per_point) OWLMI_HIP(hipMemsetAsync(a.min_row, 0x7f, (size_t)n * sizeof(int32_t), s));  // 0x7f7f7f7f: above every row (else: db_group_kernel)
@@ -1963,7 +1967,7 @@ void Engine::dbscan_auto(float eps0, int min_pts, double max_noise, int max_roun
     a.eps_wide = eps * 1.000001f;
     a.eps_in2 = eps * eps * (1.0f - 1e-5f);
     a.eps_out2 = eps * eps * (1.0f + 1e-5f);
-    OWLMI_HIP(hipMemsetAsync(counters_, 0, (kCounters + kDbStripes * 8) * sizeof(unsigned long long), s));
+    OWLMI_HIP(hipMemsetAsync(counters_, 0, kCounterWords * sizeof(unsigned long long), s));
     hipLaunchKernelGGL(db_core_kernel, dim3(blocks), dim3(kDbBlock), 0, s, a, (int32_t *)nullptr);
     {
       int32_t *pos = a.rank;

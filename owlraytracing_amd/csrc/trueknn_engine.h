@@ -111,6 +111,8 @@ class Engine {
   // counters_: kCounters words (knn_device.h) + kDbStripes x 8 words of RT-DBSCAN's work counters, striped over the workgroups
   // (dbscan.hip: a launch over 50 M points would otherwise queue 400 000 atomics on two addresses); h_counters_: 16 + the stripes
   static constexpr int kDbStripes = 32;
+  // ... + the group-union kernel's per-XCD packet cursors, kDbCursorStride words apart (a cache line each: dbscan.hip)
+  static constexpr int kDbCursorStride = 32, kCounterWords = kCounters + kDbStripes * 8 + 8 * kDbCursorStride;
   unsigned long long *counters_ = nullptr, *h_counters_ = nullptr;
   void *wave_ws_ = nullptr;
   size_t wave_ws_bytes_ = 0;
