@@ -699,7 +699,10 @@ __global__ void __launch_bounds__(kDbBlock) db_uniform_kernel(DbArgs a, const in
 // 4 MB L2: 15 GB per launch; one rope walk per packet, wave-uniform, 1.8 ms per launch -- 1 300 dependent loads in a row;
 // the stack walk needs some 40 rounds of loads per packet; with the popped nodes tested against the packet's bounding box
 // instead of its 64 groups, a packet across a jump of the Z-curve walked half the tree: one wave, 4 ms.)
-constexpr int kDbBuf = 8;
+#ifndef TKNN_DB_BUF
+#define TKNN_DB_BUF 8
+#endif
+constexpr int kDbBuf = TKNN_DB_BUF;
 #ifndef TKNN_DB_BOXES
 #define TKNN_DB_BOXES 2
 #endif
@@ -942,6 +945,14 @@ __global__ void __launch_bounds__(kDbUnionBlock) __attribute__((amdgpu_waves_per
       const int from = (xcc + t) & 7;
       if (seg_empty & (1u << from)) continue;
       unsigned long long v = 0;
+      if (t > 0) {  // another XCD's packets (mine are used up): a look before the turn -- cursors only grow, a load does not queue
+        if (lane == 0) v = __hip_atomic_load(next_packet + from * kDbCursorStride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        v = __shfl(v, 0);
+        if ((((long long)v / chunk) * 8 + from) * chunk + (long long)v % chunk >= packets) {
+          seg_empty |= 1u << from;
+          continue;
+        }
+      }
       if (lane == 0) v = atomicAdd(next_packet + from * kDbCursorStride, 1ull);
       v = __shfl(v, 0);
       const long long p = (((long long)v / chunk) * 8 + from) * chunk + (long long)v % chunk;
@@ -1752,10 +1763,11 @@ void Engine::dbscan(float eps, int min_pts, int32_t *d_labels, uint8_t *d_core, 
         db_union_resident_ = 256 * 4;
       } else {
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)db_group_union_kernel, kDbUnionBlock, 0) != hipSuccess) per_cu = 4;
-        // nine workgroups = 18 waves per CU, one fewer than fit: the launch lasts as long as its slowest packets (sparse
-        // outskirts: three times the average walk), and those run faster with fewer waves on their SIMD -- BASELINE config 3,
-        // both passes: 1.83 ms with ten, 1.74 with nine, 1.77 with eight, 1.82 with seven
-        db_union_resident_ = prop.multiProcessorCount * std::max(1, std::min(per_cu, 9));
+        // nine workgroups = 18 waves per CU are what fits (16 KB of LDS per workgroup = 13 granules of 1 280 bytes: the occupancy
+        // query says ten).  BASELINE config 3, both passes, since the packet cursors have cache lines of their own (round 4):
+        // 1.46 / 1.34 / 1.25 ms with seven / eight / nine; ten (a build with seven buffered unions per lane: 12 granules) 1.27
+        // (TKNN_DB_PER_CU: measurements)
+        db_union_resident_ = prop.multiProcessorCount * std::max(1, std::min(per_cu, getenv("TKNN_DB_PER_CU") ? atoi(getenv("TKNN_DB_PER_CU")) : 9));
       }
     }
     const int resident = db_union_resident_;

@@ -282,7 +282,7 @@ Engine::Engine() {
   OWLMI_HIP(hipEventCreate(&ev_h_));
   OWLMI_HIP(hipMalloc((void **)&counters_, kCounterWords * sizeof(unsigned long long)));  // (the team kernel's per-XCD packet counters sit in the stripes' words, 32 words apart: trueknn_team.hip) [32]: tie rows
   OWLMI_HIP(hipMalloc((void **)&tie_list_, kTieListCap * sizeof(int32_t)));
-  OWLMI_HIP(hipHostMalloc((void **)&h_counters_, (16 + kDbStripes * 8) * sizeof(unsigned long long)));
+  OWLMI_HIP(hipHostMalloc((void **)&h_counters_, (16 + std::max(kDbStripes * 8, kStatStripes * kStatStride)) * sizeof(unsigned long long)));
   if (const char *e = getenv("TKNN_WAVE_FORCE_REDO")) wave_force_redo_ = atoi(e) != 0;
   if (const char *e = getenv("TKNN_LEAF_MAX")) {
     int v = atoi(e);

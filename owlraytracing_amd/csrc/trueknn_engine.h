@@ -112,7 +112,11 @@ class Engine {
   // (dbscan.hip: a launch over 50 M points would otherwise queue 400 000 atomics on two addresses); h_counters_: 16 + the stripes
   static constexpr int kDbStripes = 32;
   // ... + the group-union kernel's per-XCD packet cursors, kDbCursorStride words apart (a cache line each: dbscan.hip)
-  static constexpr int kDbCursorStride = 32, kCounterWords = kCounters + kDbStripes * 8 + 8 * kDbCursorStride;
+  static constexpr int kDbCursorStride = 32;
+  // ... + the packet kernel's end-of-wave statistics, striped over the workgroups: kStatStripes stripes of kStatStride words
+  // (a cache line each; within a stripe the words are counters_'s [1] .. [9]), folded on the host (trueknn_team.hip)
+  static constexpr int kStatStripes = 32, kStatStride = 16, kStatBase = kCounters + kDbStripes * 8 + 8 * kDbCursorStride;
+  static constexpr int kCounterWords = kStatBase + kStatStripes * kStatStride;
   unsigned long long *counters_ = nullptr, *h_counters_ = nullptr;
   void *wave_ws_ = nullptr;
   size_t wave_ws_bytes_ = 0;

@@ -134,6 +134,10 @@ constexpr int kWalkBlocksPerCu = 4 * (TKNN_WALK_WAVES > 4 ? TKNN_WALK_WAVES : 4)
 // use during a solve).  Side by side in one cache line (round 3: counters[16 + x]) their atomics -- one per packet, 156 000 per launch
 // of the benchmark -- queued at one place (see TeamArgs::grab for what a turn at one address costs)
 constexpr int kXcdCounter = kCounters, kXcdCounterStride = 32;
+// ... and the packet kernel's end-of-wave statistics: five atomics per wave on one cache line, 20 000 at the end of a launch of the
+// benchmark, cost it 0.10 of 6.6 ms (measured by leaving them out).  Striped over the workgroups, a cache line per stripe (the layout
+// is Engine::kStatBase .. in trueknn_engine.h: behind RT-DBSCAN's words), folded by the host into h_counters_[1 .. 9]
+constexpr int kStatStripes = 32, kStatStride = 16, kStatBase = kCounters + 32 * 8 + 8 * 32;
 constexpr int kTeamStack = 192;     // wide-pyramid stack entries per wave
 constexpr int kQrecStride = 6;      // floats per LDS query record (layout below)
 constexpr int kScanBudget = 16384;  // leaf blocks one packet-level may test against its queries before it is handed over
@@ -1389,17 +1393,18 @@ __global__ void __launch_bounds__(kTeamBlock) __attribute__((amdgpu_waves_per_eu
   const unsigned long long isum = t_wave_sum(my_isect_sum), lsum = t_wave_sum((unsigned long long)my_levels), usum = t_wave_sum((unsigned long long)my_unfinished),
                            hsum = t_wave_sum((unsigned long long)my_handed);
   if (lane == 0) {
-    atomicMax(&a.counters[1], (unsigned long long)wave_levels);
-    atomicAdd(&a.counters[2], wave_node_tests);
-    atomicAdd(&a.counters[3], wave_point_tests);
-    atomicAdd(&a.counters[4], isum);
-    atomicAdd(&a.counters[6], lsum);
-    if (usum) atomicAdd(&a.counters[7], usum);
+    unsigned long long *st = a.counters + kStatBase + (blockIdx.x & (kStatStripes - 1)) * kStatStride;  // my stripe: [1] .. [9] as in counters
+    atomicMax(&st[1], (unsigned long long)wave_levels);
+    atomicAdd(&st[2], wave_node_tests);
+    atomicAdd(&st[3], wave_point_tests);
+    atomicAdd(&st[4], isum);
+    atomicAdd(&st[6], lsum);
+    if (usum) atomicAdd(&st[7], usum);
     if (hsum) {
-      atomicAdd(&a.counters[8], hsum);
-      atomicMin(&a.counters[9], (unsigned long long)wave_min_handover);
+      atomicAdd(&st[8], hsum);
+      atomicMin(&st[9], (unsigned long long)wave_min_handover);
     }
-    if (wave_err) atomicOr(&a.counters[5], (unsigned long long)wave_err);
+    if (wave_err) atomicOr(&st[5], (unsigned long long)wave_err);
 #if TKNN_DIAG_BUILD
     for (int i = 0; i < 5; i++) atomicAdd(&a.counters[10 + i], ph[i]);
     if (a.diag & 32) {
@@ -1700,6 +1705,7 @@ __global__ void __launch_bounds__(kTeamBlock) TKNN_WALK_ATTR team_walk_kernel(Te
 __global__ void __launch_bounds__(256) team_prep_kernel(uint8_t *done, uint8_t *tie, int64_t n, unsigned long long *counters, int32_t *levels) {
   const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, nth = (int64_t)gridDim.x * blockDim.x;
   if (tid < kCounters + 8 * kXcdCounterStride) counters[tid] = tid == 9 ? ~0ull : 0ull;  // (+ the per-XCD packet counters behind them)
+  if (tid < kStatStripes * kStatStride) counters[kStatBase + tid] = (tid & (kStatStride - 1)) == 9 ? ~0ull : 0ull;  // the statistics' stripes
   // hipMalloc'd arrays are 256-byte aligned: whole 16-byte words, then the last few bytes
   const int64_t words = n / 16;
   uint4 *d16 = reinterpret_cast<uint4 *>(done), *t16 = reinterpret_cast<uint4 *>(tie);
@@ -2698,9 +2704,20 @@ bool Engine::solve_team(const SolveArgs &sa, tknnSolveInfo *info, hipStream_t s)
   // before the host knows anything, so the usual handful costs no round trip of its own
   launch_tie_fix(sa, tie_list_, -1, std::min(prop.multiProcessorCount * 4, kTieListCap / 4), s);
   OWLMI_HIP(hipEventRecord(ev_c_, s));
-  OWLMI_HIP(hipMemcpyAsync(h_counters_, counters_, 10 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+  static_assert(kStatBase == Engine::kStatBase && kStatStripes == Engine::kStatStripes && kStatStride == Engine::kStatStride, "one layout");
+  OWLMI_HIP(hipMemcpyAsync(h_counters_ + 16, counters_ + kStatBase, kStatStripes * kStatStride * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
   OWLMI_HIP(hipMemcpyAsync(h_counters_ + 10, counters_ + kTieCounter, 3 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
   OWLMI_HIP(hipStreamSynchronize(s));
+  {  // the stripes of the kernel's statistics, folded into the places the single counters had
+    for (int i = 0; i < 10; i++) h_counters_[i] = i == 9 ? ~0ull : 0ull;
+    for (int j = 0; j < kStatStripes; j++) {
+      const unsigned long long *st = h_counters_ + 16 + j * kStatStride;
+      h_counters_[1] = std::max(h_counters_[1], st[1]);
+      for (int i : {2, 3, 4, 6, 7, 8}) h_counters_[i] += st[i];
+      h_counters_[5] |= st[5];
+      h_counters_[9] = std::min(h_counters_[9], st[9]);
+    }
+  }
   float ms = 0;
   OWLMI_HIP(hipEventElapsedTime(&ms, ev_a_, ev_b_));
   if (h_counters_[8] == 0 && h_counters_[10] <= (unsigned long long)kTieListCap) {  // nothing handed over, every flagged row listed
