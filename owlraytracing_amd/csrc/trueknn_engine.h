@@ -87,6 +87,9 @@ class Engine {
   void solve_bigk(const SolveArgs &sa, tknnSolveInfo *info, hipStream_t s);
   // trueknn_team.hip: redo the rows flagged in tie_ with the reference's order of exact-distance ties
   void fix_ties(const SolveArgs &sa, tknnSolveInfo *info, hipStream_t s);
+  void reset_stat_stripes(hipStream_t s);
+  void fetch_stat_stripes(hipStream_t s);
+  void fold_stat_stripes(bool with_min);
   void launch_tie_fix(const SolveArgs &sa, const int32_t *slots, int32_t nslots, int blocks, hipStream_t s,
                       const int32_t *d_slot_count = nullptr, int64_t expected_rows = 0);
   int first_step_estimate(const SolveArgs &sa) const;

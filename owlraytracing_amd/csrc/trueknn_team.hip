@@ -1689,13 +1689,14 @@ __global__ void __launch_bounds__(kTeamBlock) TKNN_WALK_ATTR team_walk_kernel(Te
                            fsum = t_wave_sum((unsigned long long)failed);
   const int ml = (int)t_wave_max((float)max_level);
   if (lane == 0) {
-    atomicMax(&a.counters[1], (unsigned long long)ml);
-    atomicAdd(&a.counters[2], nt);
-    atomicAdd(&a.counters[3], pt);
-    atomicAdd(&a.counters[4], isum);
-    atomicAdd(&a.counters[6], lsum);
-    if (usum) atomicAdd(&a.counters[7], usum);
-    if (fsum) atomicAdd(&a.counters[8], fsum);
+    unsigned long long *st = a.counters + kStatBase + (blockIdx.x & (kStatStripes - 1)) * kStatStride;  // (my stripe: see kStatBase)
+    atomicMax(&st[1], (unsigned long long)ml);
+    atomicAdd(&st[2], nt);
+    atomicAdd(&st[3], pt);
+    atomicAdd(&st[4], isum);
+    atomicAdd(&st[6], lsum);
+    if (usum) atomicAdd(&st[7], usum);
+    if (fsum) atomicAdd(&st[8], fsum);
   }
 }
 
@@ -2333,13 +2334,14 @@ __global__ void __launch_bounds__(kTeamBlock) TKNN_BIGK_ATTR bigk_walk_kernel(Te
                            fsum = t_wave_sum((unsigned long long)failed);
   const int ml = (int)t_wave_max((float)max_level);
   if (lane == 0) {
-    atomicMax(&a.counters[1], (unsigned long long)ml);
-    atomicAdd(&a.counters[2], nt);
-    atomicAdd(&a.counters[3], pt);
-    atomicAdd(&a.counters[4], isum);
-    atomicAdd(&a.counters[6], lsum);
-    if (usum) atomicAdd(&a.counters[7], usum);
-    if (fsum) atomicAdd(&a.counters[8], fsum);
+    unsigned long long *st = a.counters + kStatBase + (blockIdx.x & (kStatStripes - 1)) * kStatStride;  // (my stripe: see kStatBase)
+    atomicMax(&st[1], (unsigned long long)ml);
+    atomicAdd(&st[2], nt);
+    atomicAdd(&st[3], pt);
+    atomicAdd(&st[4], isum);
+    atomicAdd(&st[6], lsum);
+    if (usum) atomicAdd(&st[7], usum);
+    if (fsum) atomicAdd(&st[8], fsum);
   }
 }
 
@@ -2348,6 +2350,25 @@ __global__ void __launch_bounds__(kTeamBlock) TKNN_BIGK_ATTR bigk_walk_kernel(Te
 bool Engine::team_kernel_supports(int k) { return k >= 1 && k <= 64; }
 
 bool Engine::bigk_supports(int k) { return k > 64 && k <= TKNN_MAX_K; }
+
+// The team kernels' end-of-wave statistics live in stripes (kStatBase): zeroed before a launch of a walk (the packet kernel's
+// prep launch does it itself), copied behind h_counters_[16] after it and folded into h_counters_[1 .. 9] once the stream is idle
+void Engine::reset_stat_stripes(hipStream_t s) {
+  OWLMI_HIP(hipMemsetAsync(counters_ + kStatBase, 0, kStatStripes * kStatStride * sizeof(unsigned long long), s));
+}
+void Engine::fetch_stat_stripes(hipStream_t s) {
+  OWLMI_HIP(hipMemcpyAsync(h_counters_ + 16, counters_ + kStatBase, kStatStripes * kStatStride * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+}
+void Engine::fold_stat_stripes(bool with_min) {
+  for (int i = 1; i < 10; i++) h_counters_[i] = i == 9 && with_min ? ~0ull : 0ull;
+  for (int j = 0; j < kStatStripes; j++) {
+    const unsigned long long *st = h_counters_ + 16 + j * kStatStride;
+    h_counters_[1] = std::max(h_counters_[1], st[1]);
+    for (int i : {2, 3, 4, 6, 7, 8}) h_counters_[i] += st[i];
+    h_counters_[5] |= st[5];
+    if (with_min) h_counters_[9] = std::min(h_counters_[9], st[9]);
+  }
+}
 
 // k > 64: every query through bigk_walk_kernel, one query per team, the k-lists in memory (one per resident team)
 void Engine::solve_bigk(const SolveArgs &sa, tknnSolveInfo *info, hipStream_t s) {
@@ -2401,6 +2422,7 @@ void Engine::solve_bigk(const SolveArgs &sa, tknnSolveInfo *info, hipStream_t s)
   OWLMI_HIP(hipMemsetAsync(isect_sorted_, 0, (size_t)n * sizeof(int64_t), s));
   OWLMI_HIP(hipMemsetAsync(next_level_, 0, (size_t)n * sizeof(int32_t), s));
   if (sa.d_levels && sa.phase < 2) OWLMI_HIP(hipMemsetAsync(sa.d_levels, 0xff, (size_t)n * sizeof(int32_t), s));  // (phases 2, 3 complete an earlier call's rows)
+  reset_stat_stripes(s);
   OWLMI_HIP(hipEventRecord(ev_a_, s));
   {
     BigKey *lists = (BigKey *)wave_ws_;
@@ -2411,8 +2433,9 @@ void Engine::solve_bigk(const SolveArgs &sa, tknnSolveInfo *info, hipStream_t s)
   }
   OWLMI_HIP(hipGetLastError());
   OWLMI_HIP(hipEventRecord(ev_b_, s));
-  OWLMI_HIP(hipMemcpyAsync(h_counters_, counters_, 10 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+  fetch_stat_stripes(s);
   OWLMI_HIP(hipStreamSynchronize(s));
+  fold_stat_stripes(false);
   float ms = 0;
   OWLMI_HIP(hipEventElapsedTime(&ms, ev_a_, ev_b_));
   if (h_counters_[8]) throw ArgError{TKNN_E_UNSUPPORTED, "k > 64: a query's walk outgrew its stack (a pyramid of more than six levels?)"};
@@ -2629,6 +2652,7 @@ bool Engine::solve_team(const SolveArgs &sa, tknnSolveInfo *info, hipStream_t s)
     if (sa.d_levels) OWLMI_HIP(hipMemsetAsync(sa.d_levels, 0xff, (size_t)n * sizeof(int32_t), s));
     const int walk_blocks = (int)std::min<int64_t>((n + 3) / 4, (int64_t)prop.multiProcessorCount * kWalkBlocksPerCu);
     a.grab = 1;  // (queries differ too much for longer turns: measured, see TeamArgs::grab)
+    reset_stat_stripes(s);
     OWLMI_HIP(hipEventRecord(ev_a_, s));
     if (with_halo)
       hipLaunchKernelGGL((team_walk_kernel<true, 4>), dim3(walk_blocks), dim3(kTeamBlock), 0, s, a, (const int32_t *)nullptr, (int32_t)n);
@@ -2636,8 +2660,9 @@ bool Engine::solve_team(const SolveArgs &sa, tknnSolveInfo *info, hipStream_t s)
       hipLaunchKernelGGL((team_walk_kernel<false, 4>), dim3(walk_blocks), dim3(kTeamBlock), 0, s, a, (const int32_t *)nullptr, (int32_t)n);
     OWLMI_HIP(hipGetLastError());
     OWLMI_HIP(hipEventRecord(ev_b_, s));
-    OWLMI_HIP(hipMemcpyAsync(h_counters_, counters_, 10 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+    fetch_stat_stripes(s);
     OWLMI_HIP(hipStreamSynchronize(s));
+    fold_stat_stripes(false);
     float ms = 0;
     OWLMI_HIP(hipEventElapsedTime(&ms, ev_a_, ev_b_));
     tknnSolveInfo mine;
@@ -2705,19 +2730,11 @@ bool Engine::solve_team(const SolveArgs &sa, tknnSolveInfo *info, hipStream_t s)
   launch_tie_fix(sa, tie_list_, -1, std::min(prop.multiProcessorCount * 4, kTieListCap / 4), s);
   OWLMI_HIP(hipEventRecord(ev_c_, s));
   static_assert(kStatBase == Engine::kStatBase && kStatStripes == Engine::kStatStripes && kStatStride == Engine::kStatStride, "one layout");
-  OWLMI_HIP(hipMemcpyAsync(h_counters_ + 16, counters_ + kStatBase, kStatStripes * kStatStride * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+  fetch_stat_stripes(s);
   OWLMI_HIP(hipMemcpyAsync(h_counters_ + 10, counters_ + kTieCounter, 3 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
   OWLMI_HIP(hipStreamSynchronize(s));
-  {  // the stripes of the kernel's statistics, folded into the places the single counters had
-    for (int i = 0; i < 10; i++) h_counters_[i] = i == 9 ? ~0ull : 0ull;
-    for (int j = 0; j < kStatStripes; j++) {
-      const unsigned long long *st = h_counters_ + 16 + j * kStatStride;
-      h_counters_[1] = std::max(h_counters_[1], st[1]);
-      for (int i : {2, 3, 4, 6, 7, 8}) h_counters_[i] += st[i];
-      h_counters_[5] |= st[5];
-      h_counters_[9] = std::min(h_counters_[9], st[9]);
-    }
-  }
+  h_counters_[0] = 0;
+  fold_stat_stripes(true);
   float ms = 0;
   OWLMI_HIP(hipEventElapsedTime(&ms, ev_a_, ev_b_));
   if (h_counters_[8] == 0 && h_counters_[10] <= (unsigned long long)kTieListCap) {  // nothing handed over, every flagged row listed
@@ -2820,6 +2837,7 @@ bool Engine::solve_team(const SolveArgs &sa, tknnSolveInfo *info, hipStream_t s)
       }
       OWLMI_HIP(hipcub::DeviceSelect::Flagged(wave_ws_, tmp_bytes, iota, flags, slot_list_, d_count, (int)n, s));
       OWLMI_HIP(hipMemsetAsync(counters_, 0, 16 * sizeof(unsigned long long), s));
+      reset_stat_stripes(s);
       const int walk_blocks = (int)std::min<int64_t>((int64_t)(handed + 3) / 4, (int64_t)prop.multiProcessorCount * kWalkBlocksPerCu);
       OWLMI_HIP(hipEventRecord(ev_a_, s));
       {
@@ -2834,8 +2852,9 @@ bool Engine::solve_team(const SolveArgs &sa, tknnSolveInfo *info, hipStream_t s)
       }
       OWLMI_HIP(hipGetLastError());
       OWLMI_HIP(hipEventRecord(ev_b_, s));
-      OWLMI_HIP(hipMemcpyAsync(h_counters_, counters_, 10 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+      fetch_stat_stripes(s);
       OWLMI_HIP(hipStreamSynchronize(s));
+      fold_stat_stripes(false);
       float walk_ms = 0;
       OWLMI_HIP(hipEventElapsedTime(&walk_ms, ev_a_, ev_b_));
       tail.rounds = (int)h_counters_[1];
