@@ -50,6 +50,11 @@ __device__ __forceinline__ int32_t knn_key_prim(uint64_t key) {
 constexpr int kTieCounter = 32;  // no kernel's own counter reset reaches this far
 constexpr int kCounters = 40;
 constexpr int kTieListCap = 4096;
+// End-of-wave / end-of-workgroup statistics of the TrueKNN kernels live in STRIPES behind RT-DBSCAN's words of the counter array
+// (Engine::kStatBase): kStatStripes stripes of kStatStride words, a cache line each, a workgroup adds to the stripe of its index
+// and the host folds them.  All on one line they were a third of the lane kernel's time (10 M points, k = 10: 44.9 ms with, 29.7
+// without its seven atomics per wave, 1.1 M a launch at ~12 ns each) and 1.5 % of the packet kernel's.
+constexpr int kStatStripes = 32, kStatStride = 16, kStatBase = kCounters + 32 * 8 + 8 * 32;
 // edge: one of the tied candidates may be the best one LEFT OUT of the row (or the kernel cannot tell): only a walk finds it.
 // Without it every tie lies between two written entries, and tie_fix_kernel first looks whether the pairs' candidates became
 // candidates at the same level (coincident points -- duplicates of a data set -- always do): then the row stands as it is.

@@ -173,17 +173,24 @@ __global__ void __launch_bounds__(kLaneBlock) lane_round_kernel(LaneRoundArgs a)
     sc += __shfl_xor(sc, off);
     sc2 += __shfl_xor(sc2, off);
   }
+  // the workgroup's sums in LDS, then one atomic per counter and workgroup on the workgroup's stripe (kStatBase, knn_device.h)
+  __shared__ unsigned long long blk_sum[7];
+  if (threadIdx.x < 7) blk_sum[threadIdx.x] = 0ull;
+  __syncthreads();
   if ((threadIdx.x & 63) == 0) {
-    if (unfinished) atomicAdd(&a.counters[0], unfinished);
-    if (nt) atomicAdd(&a.counters[1], nt);
-    if (pt) atomicAdd(&a.counters[2], pt);
-    if (si) atomicAdd(&a.counters[3], si);
-    if (traced) atomicAdd(&a.counters[4], traced);
+    if (unfinished) atomicAdd(&blk_sum[0], unfinished);
+    if (nt) atomicAdd(&blk_sum[1], nt);
+    if (pt) atomicAdd(&blk_sum[2], pt);
+    if (si) atomicAdd(&blk_sum[3], si);
+    if (traced) atomicAdd(&blk_sum[4], traced);
     if (sc) {
-      atomicAdd(&a.counters[5], sc);
-      atomicAdd(&a.counters[6], sc2);
+      atomicAdd(&blk_sum[5], sc);
+      atomicAdd(&blk_sum[6], sc2);
     }
   }
+  __syncthreads();
+  if (threadIdx.x < 7 && blk_sum[threadIdx.x])
+    atomicAdd(&a.counters[kStatBase + (blockIdx.x & (kStatStripes - 1)) * kStatStride + threadIdx.x], blk_sum[threadIdx.x]);
 }
 
 template <int K>
@@ -409,6 +416,8 @@ void Engine::lane_rounds(const SolveArgs &sa, int first_level, bool fresh, tknnS
     if (sa.d_levels) OWLMI_HIP(hipMemsetAsync(sa.d_levels, 0xff, (size_t)n * sizeof(int32_t), s));
   }
   OWLMI_HIP(hipMemsetAsync(counters_, 0, 16 * sizeof(unsigned long long), s));
+  static_assert(kStatBase == owlmi::kStatBase && kStatStripes == owlmi::kStatStripes && kStatStride == owlmi::kStatStride, "one layout (knn_device.h)");
+  reset_stat_stripes(s);
   LaneRoundArgs a;
   a.bvh = bvh_.view();
   a.halo = halo_view();
@@ -444,7 +453,8 @@ void Engine::lane_rounds(const SolveArgs &sa, int first_level, bool fresh, tknnS
     // the box an average candidate test worked in, times 2^dims -- and for the first round from
     // the scene's mean density.
     const bool subtrees = !fresh || predicted_candidates >= 256.0;
-    OWLMI_HIP(hipMemsetAsync(counters_, 0, sizeof(unsigned long long), s));  // [0] only
+    // (the kernel's counters are striped: [0] of every stripe = unfinished is reset per round, the others accumulate over the rounds)
+    OWLMI_HIP(hipMemset2DAsync(counters_ + kStatBase, kStatStride * sizeof(unsigned long long), 0, sizeof(unsigned long long), kStatStripes, s));
     OWLMI_HIP(hipEventRecord(ev_a_, s));
     switch (cap) {
       case 1: launch_lane<1>(a, subtrees, s); break;
@@ -461,8 +471,12 @@ void Engine::lane_rounds(const SolveArgs &sa, int first_level, bool fresh, tknnS
     OWLMI_HIP(hipGetLastError());
     OWLMI_HIP(hipEventRecord(ev_b_, s));
     // hostCode.cpp:310-330: the host decides about another round from the result state
-    OWLMI_HIP(hipMemcpyAsync(h_counters_, counters_, 7 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+    fetch_stat_stripes(s);
     OWLMI_HIP(hipStreamSynchronize(s));
+    for (int i = 0; i < 7; i++) {
+      h_counters_[i] = 0;
+      for (int j = 0; j < kStatStripes; j++) h_counters_[i] += h_counters_[16 + j * kStatStride + i];
+    }
     float ms = 0;
     OWLMI_HIP(hipEventElapsedTime(&ms, ev_a_, ev_b_));
     total_ms += ms;

@@ -137,7 +137,7 @@ constexpr int kXcdCounter = kCounters, kXcdCounterStride = 32;
 // ... and the packet kernel's end-of-wave statistics: five atomics per wave on one cache line, 20 000 at the end of a launch of the
 // benchmark, cost it 0.10 of 6.6 ms (measured by leaving them out).  Striped over the workgroups, a cache line per stripe (the layout
 // is Engine::kStatBase .. in trueknn_engine.h: behind RT-DBSCAN's words), folded by the host into h_counters_[1 .. 9]
-constexpr int kStatStripes = 32, kStatStride = 16, kStatBase = kCounters + 32 * 8 + 8 * 32;
+// (kStatStripes, kStatStride, kStatBase: knn_device.h)
 constexpr int kTeamStack = 192;     // wide-pyramid stack entries per wave
 constexpr int kQrecStride = 6;      // floats per LDS query record (layout below)
 constexpr int kScanBudget = 16384;  // leaf blocks one packet-level may test against its queries before it is handed over
