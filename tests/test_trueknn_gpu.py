@@ -454,6 +454,12 @@ def test_argument_errors_are_reported_not_hidden():
     with pytest.raises(_lib.TknnError) as e:
         eng.solve(3, 1e-30, max_rounds=3)
     assert e.value.code == -4
+    # ... and capped at 127 (the tie flags keep the finishing level in seven bits): a start radius that needs 100 doublings is
+    # served, and asking for a million rounds is the same as asking for 127
+    far = eng.solve(3, 1e-30, max_rounds=1_000_000, kernel=_lib.KERNEL_TEAM)
+    assert 90 <= far["info"]["rounds"] <= 127 and far["info"]["unfinished"] == 0
+    ref = oracle.trueknn(xyz, 3, 1e-30, max_rounds=127)
+    assert_rows_equal(far["idx"].cpu().numpy(), far["dist"].cpu().numpy(), ref["idx"], ref["dist"])
     eng.close()
 
 
